@@ -1,0 +1,235 @@
+"""Mesh containers and synthetic mesh generators.
+
+`Interpolator.load_mesh(mesh_obj=...)` is duck-typed exactly as in the reference
+(`interpolator.pyx:258,291-294,333-361,217-227,433-447,454`): anything with `.points`,
+`.cells` (blocks with `.type` / `.data`), `.cell_data`, `.cell_data_dict`, `.point_data` works --
+a real `meshio.Mesh` included.  `Mesh` / `CellBlock` below are the minimal containers of that
+shape used by our own generators (meshio is not a dependency of this package).
+
+The reference ships no mesh files (`tests/mesh/.gitkeep`), so the generators here are ours:
+structured hexahedra, the Kuhn 6-tetrahedra split, wedges, and a conforming hex | pyramid+tet |
+tet mix.  Node numbering is x-fastest, z-slowest so a contiguous node block is a z-slab.
+"""
+import numpy as np
+
+
+class CellBlock:
+    def __init__(self, type, data):
+        self.type = type
+        self.data = np.ascontiguousarray(data)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __repr__(self):
+        return f"<CellBlock {self.type} x{len(self.data)}>"
+
+
+class Mesh:
+    """points (P, 3); cells: list of CellBlock; point_data {name: (P,) array};
+    cell_data {name: [array per block]} -- the meshio.Mesh layout."""
+
+    def __init__(self, points, cells, point_data=None, cell_data=None):
+        self.points = np.asarray(points)
+        self.cells = [c if hasattr(c, "type") else CellBlock(*c) for c in cells]
+        self.point_data = dict(point_data or {})
+        self.cell_data = dict(cell_data or {})
+
+    @property
+    def cell_data_dict(self):
+        return {k: {cb.type: a for cb, a in zip(self.cells, v)} for k, v in self.cell_data.items()}
+
+    @property
+    def n_cells(self):
+        return sum(len(c) for c in self.cells)
+
+
+# ------------------------------------------------------------------------------------------------
+# structured generators
+# ------------------------------------------------------------------------------------------------
+
+def _lattice_points(nx, ny, nz, lengths, origin, jitter, seed):
+    x = np.linspace(0.0, lengths[0], nx + 1) + origin[0]
+    y = np.linspace(0.0, lengths[1], ny + 1) + origin[1]
+    z = np.linspace(0.0, lengths[2], nz + 1) + origin[2]
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    if jitter:
+        rng = np.random.default_rng(seed)
+        h = np.array([lengths[0] / nx, lengths[1] / ny, lengths[2] / nz])
+        d = rng.uniform(-jitter, jitter, size=pts.shape) * h
+        # keep the box: boundary nodes only move inside their boundary plane
+        I = np.arange(pts.shape[0])
+        i = I % (nx + 1)
+        j = (I // (nx + 1)) % (ny + 1)
+        k = I // ((nx + 1) * (ny + 1))
+        d[(i == 0) | (i == nx), 0] = 0.0
+        d[(j == 0) | (j == ny), 1] = 0.0
+        d[(k == 0) | (k == nz), 2] = 0.0
+        pts = pts + d
+    return np.ascontiguousarray(pts)
+
+
+def _hex_corner_ids(nx, ny, nz, i0=0, i1=None):
+    """(E, 8) node ids of the lattice cells i0 <= i < i1 in meshio hexahedron order:
+    0=(i,j,k) 1=(i+1,j,k) 2=(i+1,j+1,k) 3=(i,j+1,k), 4..7 the same at k+1.  Cell order x-fastest."""
+    if i1 is None:
+        i1 = nx
+    sx, sy = nx + 1, (nx + 1) * (ny + 1)
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(i0, i1), indexing="ij")
+    n0 = (i + j * sx + k * sy).ravel().astype(np.int64)
+    off = np.array([0, 1, 1 + sx, sx, sy, sy + 1, sy + 1 + sx, sy + sx], dtype=np.int64)
+    return n0[:, None] + off[None, :]
+
+
+def hex_mesh(nx, ny=None, nz=None, lengths=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0),
+             jitter=0.0, seed=0):
+    """nx*ny*nz hexahedra on a box."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    pts = _lattice_points(nx, ny, nz, lengths, origin, jitter, seed)
+    return Mesh(pts, [CellBlock("hexahedron", _hex_corner_ids(nx, ny, nz))])
+
+
+# the six Kuhn simplices of the unit cube as paths 0 -> 6 through hexahedron-local corners,
+# each re-ordered to positive orientation
+_KUHN = np.array([
+    [0, 1, 2, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 7, 4, 6], [0, 4, 5, 6], [0, 5, 1, 6],
+], dtype=np.int64)
+
+
+def _kuhn_from_hex(hexes):
+    return hexes[:, _KUHN].reshape(-1, 4)
+
+
+def tet_mesh(nx, ny=None, nz=None, lengths=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0),
+             jitter=0.0, seed=0):
+    """Kuhn split: 6 tetrahedra per lattice cell around the 0-6 diagonal (conforming)."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    pts = _lattice_points(nx, ny, nz, lengths, origin, jitter, seed)
+    return Mesh(pts, [CellBlock("tetra", _kuhn_from_hex(_hex_corner_ids(nx, ny, nz)))])
+
+
+def wedge_mesh(nx, ny=None, nz=None, lengths=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0),
+               jitter=0.0, seed=0):
+    """2 wedges per lattice cell, split along the 0-2 diagonal of the bottom quad."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    pts = _lattice_points(nx, ny, nz, lengths, origin, jitter, seed)
+    h = _hex_corner_ids(nx, ny, nz)
+    w = np.stack([h[:, [0, 1, 2, 4, 5, 6]], h[:, [0, 2, 3, 4, 6, 7]]], axis=1).reshape(-1, 6)
+    return Mesh(pts, [CellBlock("wedge", w)])
+
+
+def mixed_mesh(nx, ny=None, nz=None, n_hex=None, lengths=(1.0, 1.0, 1.0), jitter=0.0, seed=0):
+    """Conforming hex | transition | tet mesh along x.
+
+    Lattice columns i < n_hex stay hexahedra; column i == n_hex is the transition layer: each cell
+    gets a centre node and six pyramids (quad faces meet the hexahedra and each other), and the
+    pyramid on the +x face is cut into two tetrahedra along the diagonal the Kuhn split uses there;
+    columns i > n_hex are Kuhn tetrahedra.  Blocks are [hexahedron, pyramid, tetra] (meshio order of
+    appearance), so the global cell numbering is the concatenation in that order.
+    """
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    n_hex = nx // 2 if n_hex is None else n_hex
+    assert 0 < n_hex < nx - 1
+    pts = _lattice_points(nx, ny, nz, lengths, (0.0, 0.0, 0.0), jitter, seed)
+    hexes = _hex_corner_ids(nx, ny, nz, 0, n_hex)
+    trans = _hex_corner_ids(nx, ny, nz, n_hex, n_hex + 1)
+    tets_src = _hex_corner_ids(nx, ny, nz, n_hex + 1, nx)
+    centres = pts[trans].mean(axis=1)
+    c_id = pts.shape[0] + np.arange(trans.shape[0], dtype=np.int64)
+    pts = np.vstack([pts, centres])
+    # pyramid base = the hexahedron face reversed (so its own base face [0,3,2,1] points outward)
+    hex_faces = np.array([[0, 3, 2, 1], [4, 5, 6, 7], [0, 1, 5, 4], [1, 2, 6, 5],
+                          [2, 3, 7, 6], [3, 0, 4, 7]])
+    pyr, tet_extra = [], []
+    for f in hex_faces:
+        base = trans[:, f[::-1]]
+        if set(f.tolist()) == {1, 2, 6, 5}:          # the +x face: two tetrahedra, diagonal 1-6
+            # base (reversed face) = [5, 6, 2, 1]; Kuhn cuts the quad {1,2,6,5} along 1-6
+            q = trans
+            tet_extra.append(np.stack([q[:, 1], q[:, 6], q[:, 2], c_id], axis=1))
+            tet_extra.append(np.stack([q[:, 1], q[:, 5], q[:, 6], c_id], axis=1))
+        else:
+            pyr.append(np.concatenate([base, c_id[:, None]], axis=1))
+    pyr = np.stack(pyr, axis=1).reshape(-1, 5)
+    tet_extra = np.stack(tet_extra, axis=1).reshape(-1, 4)
+    tets = np.vstack([tet_extra, _kuhn_from_hex(tets_src)])
+    tets = _fix_tet_orientation(pts, tets)
+    return Mesh(pts, [CellBlock("hexahedron", hexes), CellBlock("pyramid", pyr),
+                      CellBlock("tetra", tets)])
+
+
+def _fix_tet_orientation(pts, tets):
+    a, b, c, d = (pts[tets[:, i]] for i in range(4))
+    vol = np.einsum("ij,ij->i", np.cross(b - a, c - a), d - a)
+    neg = vol < 0
+    tets = tets.copy()
+    tets[neg, 1], tets[neg, 2] = tets[neg, 2].copy(), tets[neg, 1].copy()
+    return tets
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic fields (the shapes the reference's analytical cases use, tests/utils/analytical.py)
+# ------------------------------------------------------------------------------------------------
+
+def cell_centroids(mesh):
+    """vertex mean per cell, block order (what analytical.py:142 evaluates K at)."""
+    return np.vstack([mesh.points[c.data].mean(axis=1) for c in mesh.cells])
+
+
+def permeability_alh(centroids):
+    """Heterogeneous SPD tensor of the ALH case (tests/utils/analytical.py:303-323)."""
+    x, y, z = centroids[:, 0], centroids[:, 1], centroids[:, 2]
+    K = np.zeros((len(x), 3, 3))
+    K[:, 0, 0] = y ** 2 + z ** 2 + 1
+    K[:, 0, 1] = -x * y
+    K[:, 0, 2] = -x * z
+    K[:, 1, 0] = -y * x
+    K[:, 1, 1] = x ** 2 + z ** 2 + 1
+    K[:, 1, 2] = -y * z
+    K[:, 2, 0] = -z * x
+    K[:, 2, 1] = -z * y
+    K[:, 2, 2] = x ** 2 + y ** 2 + 1
+    return K
+
+
+def permeability_const(n, kind="LIN"):
+    """Constant tensors of the LIN/QUAD and FAN cases (analytical.py:253-296)."""
+    if kind == "FAN":
+        Ku = np.array([[2464.36, 0.0, 1148.68], [0.0, 536.64, 0.0], [1148.68, 0.0, 536.64]])
+    else:
+        Ku = np.array([[1.0, 0.5, 0.0], [0.5, 1.0, 0.5], [0.0, 0.5, 1.0]])
+    K = np.zeros((n, 3, 3))
+    K[:] = Ku
+    return K
+
+
+def attach_fields(mesh, variable="u", perm="ALH", neumann_plane=None, seed=1, values=None):
+    """Attach `permeability`, a scalar cell variable and the Neumann point arrays to `mesh`.
+
+    neumann_plane: None (all-Dirichlet boundary, flags 0) or (axis, coordinate): nodes with
+    |x[axis] - coordinate| < 1e-12 get flag 1 and a U(0,1) Neumann value (default_rng(seed)).
+    """
+    cen = cell_centroids(mesh)
+    E = cen.shape[0]
+    K = permeability_alh(cen) if perm == "ALH" else permeability_const(E, perm)
+    K = K.reshape(E, 9)
+    if values is None:
+        values = cen[:, 0] + cen[:, 1] + cen[:, 2]
+    P = mesh.points.shape[0]
+    flag = np.zeros(P)
+    val = np.zeros(P)
+    if neumann_plane is not None:
+        axis, coord = neumann_plane
+        on = np.abs(mesh.points[:, axis] - coord) < 1e-12
+        flag[on] = 1.0
+        val[on] = np.random.default_rng(seed).uniform(0.0, 1.0, int(on.sum()))
+    sizes = np.cumsum([0] + [len(c) for c in mesh.cells])
+    split = lambda a: [a[sizes[b]:sizes[b + 1]] for b in range(len(mesh.cells))]
+    mesh.cell_data = {"permeability": split(K), variable: split(np.asarray(values, dtype=float))}
+    mesh.point_data = {"neumann_flag_" + variable: flag, "neumann_" + variable: val}
+    return mesh

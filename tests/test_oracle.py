@@ -1,0 +1,89 @@
+"""The oracle is pinned here: the C restatement (oracle/ninpol_oracle.c) against
+ (1) the committed golden fixtures, which are outputs of the reference's own compiled code, and
+ (2) the reference itself (oracle/_ref) on larger generated meshes, when _ref has been built.
+Integers and geometry bit-exact, IDW / LS bit-exact (NaNs included), GLS within 1e-10 row-relative
+(two Householder QR codes agree to ~kappa*eps; SciPy's LAPACK is third-party)."""
+import numpy as np
+import pytest
+
+import util
+from ninpol_amd import mesh as M
+
+
+@pytest.mark.parametrize("case", util.GOLDEN_CASES)
+def test_port_matches_golden(oracle_lib, case):
+    mesh, z = util.load_golden(case)
+    o = oracle_lib.OracleInterpolator("port", threads=2)
+    o.load_mesh(mesh)
+    util.assert_grid_equal(o.grid, z)
+    np.testing.assert_array_equal(o.cells_data, z["cells_data"])
+    np.testing.assert_array_equal(o.points_data, z["points_data"])
+    assert list(o.variable_to_index["cells"]) == [str(s) for s in z["cells_vars"]]
+    assert list(o.variable_to_index["points"]) == [str(s) for s in z["points_vars"]]
+    for meth in ("idw", "ls", "gls"):
+        w, nw = o.prepare(meth, "u")
+        if meth in ("idw", "ls"):
+            np.testing.assert_array_equal(w, z[f"{meth}_weights"])
+        else:
+            assert util.rowscaled_err(w, z[f"{meth}_weights"]) <= util.WEIGHT_RTOL
+            assert util.rowscaled_err(nw, z[f"{meth}_neumann_ws"]) <= util.WEIGHT_RTOL
+        W, _ = o.interpolate("u", meth)
+        assert W.shape == (o.grid.n_points, o.grid.n_elems)
+        err = util.csr_rowscaled_err(W, z[f"{meth}_indptr"], z[f"{meth}_indices"], z[f"{meth}_data"])
+        assert err <= util.WEIGHT_RTOL, (meth, err)
+
+
+def _meshes():
+    yield "hex12_jitter", M.hex_mesh(12, jitter=0.15, seed=0), "ALH", (2, 0.0)
+    yield "hex10_uniform_neu", M.hex_mesh(10), "LIN", (0, 1.0)
+    yield "tet5_jitter", M.tet_mesh(5, jitter=0.1, seed=1), "ALH", (1, 0.0)
+    yield "wedge5", M.wedge_mesh(5, 4, 3, jitter=0.05, seed=2), "ALH", None
+    yield "mixed844", M.mixed_mesh(8, 4, 4, jitter=0.1, seed=3), "ALH", (2, 1.0)
+
+
+@pytest.mark.parametrize("name,mesh,perm,plane", list(_meshes()), ids=[m[0] for m in _meshes()])
+def test_port_matches_reference(oracle_lib, name, mesh, perm, plane):
+    if not oracle_lib.have_reference():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    M.attach_fields(mesh, "u", perm=perm, neumann_plane=plane, seed=7)
+    a = oracle_lib.OracleInterpolator("port", threads=2)
+    b = oracle_lib.OracleInterpolator("reference")
+    a.load_mesh(mesh)
+    b.load_mesh(mesh)
+    for k in util.GRID_SCALARS:
+        assert getattr(a.grid, k) == getattr(b.grid, k), k
+    for k in util.GRID_ARRAYS:
+        np.testing.assert_array_equal(getattr(a.grid, k), getattr(b.grid, k), err_msg=k)
+    for meth in ("idw", "ls", "gls"):
+        wa, na = a.prepare(meth, "u")
+        wb, nb = b.prepare(meth, "u")
+        if meth == "gls":
+            assert util.rowscaled_err(wa, wb) <= util.WEIGHT_RTOL
+            assert util.rowscaled_err(na, nb) <= util.WEIGHT_RTOL
+        else:
+            np.testing.assert_array_equal(wa, wb)
+
+
+def test_reference_quirks(oracle_lib):
+    """(b) neumann_ws = last cell's weight, (c) it is added to every stored entry,
+    (d) Dirichlet boundary rows vanish, degenerate corner (n_bface >= n_face) gives a zero row."""
+    mesh, z = util.load_golden("hex4_uniform")
+    o = oracle_lib.OracleInterpolator("port", threads=1)
+    o.load_mesh(mesh)
+    w, nw = o.prepare("gls", "u")
+    g = o.grid
+    flag = mesh.point_data["neumann_flag_u"].astype(bool)
+    deg = np.diff(g.esup_ptr)
+    neu = np.where(flag)[0]
+    corner = [p for p in neu if deg[p] == 1]
+    assert corner and all(nw[p] == 0.0 and not w[p].any() for p in corner)
+    for p in neu:
+        if deg[p] > 1:
+            assert nw[p] == w[p, deg[p] - 1]
+    W, _ = o.interpolate("u", "gls")
+    dirichlet = np.where((g.boundary_points == 1) & ~flag)[0]
+    assert np.all(np.diff(W.indptr)[dirichlet] == 0)
+    p = next(p for p in neu if deg[p] > 1)
+    row = W[p].toarray().ravel()
+    last_cell = g.esup[g.esup_ptr[p + 1] - 1]
+    assert row[last_cell] == 2.0 * nw[p]
