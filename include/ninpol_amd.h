@@ -1,0 +1,133 @@
+/*
+ * ninpol_amd.h -- C ABI of libninpol_amd.so: the MI355X-native nodal-interpolation hot path.
+ *
+ * The reference (daviyan5/ninpol) has no C ABI: its extension points are the Python class
+ * `ninpol.Interpolator` and the in-process Cython method-plugin convention
+ *     prepare(Grid grid, cells_data, points_data, faces_data, variable_to_index, variable,
+ *             target_points, weights[out], neumann_ws[out])
+ * (ninpol/_methods/idw.pxd:19-24, ls.pxd:20-25, gls.pxd:22-27; called at
+ * ninpol/_interpolator/interpolator.pyx:657-665).  The entry points below are what a ctypes / cgo /
+ * Cython binding for that path binds instead; each cites the reference interface it replaces.
+ * Plain pointers and sizes only: no Python, numpy or torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative NIN_E* code; nin_last_error() gives text.
+ *     Nothing throws, nothing aborts (the reference's inner helpers are `noexcept nogil` too).
+ *   - index arrays crossing the boundary are int64 (`ctypedef long long DTYPE_I_t`, grid.pxd:13),
+ *     reals are float64 (grid.pxd:14); inside the library and on the device indices are int32.
+ *   - "host" pointers are ordinary memory owned by the caller; "dev" pointers are HIP device
+ *     pointers (e.g. torch tensor .data_ptr()) owned by the caller; `stream` is a hipStream_t passed
+ *     as void* (NULL = the null stream).
+ *   - a nin_grid is NOT thread-safe (like one reference Interpolator instance); distinct handles are
+ *     independent.
+ */
+#ifndef NINPOL_AMD_H
+#define NINPOL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nin_grid nin_grid; /* host connectivity + geometry (+ device mirror once uploaded) */
+
+enum {
+    NIN_OK = 0,
+    NIN_EINVAL = -1,   /* bad argument (NULL, negative size, unknown name / method)            */
+    NIN_ENOMEM = -2,   /* host or device allocation failed                                       */
+    NIN_EHIP = -3,     /* a HIP runtime call failed (text in nin_last_error)                     */
+    NIN_ENODEVICE = -4,/* no usable GPU / grid not uploaded: the product path has no CPU fallback */
+    NIN_ERANGE = -5,   /* a count does not fit the int32 device layout, or a node is too large   */
+    NIN_ESTATE = -6    /* call order (fields not set, grid not built ...)                        */
+};
+
+enum { NIN_METHOD_GLS = 0, NIN_METHOD_IDW = 1, NIN_METHOD_LS = 2 }; /* interpolator.pyx:60-64 order */
+
+/* dtype codes reported by nin_grid_array */
+enum { NIN_I64 = 0, NIN_F64 = 1 };
+
+const char *nin_last_error(void);
+const char *nin_version(void);
+
+/* ---- Grid: connectivity + geometry, built once on the host ---------------------------------
+ * Replaces Grid.__cinit__ (grid.pyx:47-140) + Grid.build() (:142-231) + load_point_coords (:661)
+ * + calculate_centroids (:669) + calculate_normal_faces (:721), i.e. interpolator.pyx:194,204-207.
+ * Arguments are the reference's Grid ctor arguments (same meaning, same -1 padding):
+ *   npoel[8], nfael[8], lnofa[8][6], lpofa[8][6][4], nedel[8], lpoed[8][12][2],
+ *   connectivity[n_elems][8], element_types[n_elems], coords[n_points][coords_dim].
+ * Results are bit-identical to the reference's for conforming meshes (integers, float64 centroids
+ * and face centres, float32-valued normals and areas).  num_threads <= 0 picks the OpenMP default. */
+int nin_grid_create(int64_t dim, int64_t n_elems, int64_t n_points,
+                    const int64_t *npoel, const int64_t *nfael, const int64_t *lnofa,
+                    const int64_t *lpofa, const int64_t *nedel, const int64_t *lpoed,
+                    const int64_t *connectivity, const int64_t *element_types,
+                    const double *coords, int coords_dim, int build_edges, int num_threads,
+                    nin_grid **out);
+void nin_grid_destroy(nin_grid *g);
+
+/* Readonly attributes of Grid (grid.pxd:128-187).  Scalars: dim n_elems n_points n_faces n_edges
+ * MX_ELEMENTS_PER_POINT MX_POINTS_PER_POINT MX_ELEMENTS_PER_FACE MX_FACES_PER_POINT.  Unknown -> -1. */
+int64_t nin_grid_scalar(const nin_grid *g, const char *name);
+
+/* Number of elements of array `name` and its dtype code; arrays: esup esup_ptr psup psup_ptr fsup
+ * fsup_ptr esuf esuf_ptr esuel infael inpofa inpoel inpoed inedel boundary_faces boundary_points
+ * point_coords centroids faces_centers normal_faces faces_areas element_types. */
+int nin_grid_array_info(nin_grid *g, const char *name, int64_t *count, int *dtype);
+/* Copy array `name` into caller memory of `count` elements (int64 or float64 as reported). */
+int nin_grid_array_copy(nin_grid *g, const char *name, void *dst, int64_t count);
+
+/* ---- device residency --------------------------------------------------------------------- */
+int nin_device_count(int *count);
+/* Push the CSR connectivity (esup, fsup), the per-face pair/centre/normal and the geometry to the
+ * HBM of `device` in the canonical int32 / SoA layout.  north_star: "built once as CSR
+ * on host and pushed to HBM". */
+int nin_grid_to_device(nin_grid *g, int device);
+int nin_grid_device(const nin_grid *g); /* device id or -1 */
+
+/* Per-call fields the plugins read from the data tables (idw.pyx:27-28, ls.pyx:27-28,
+ * gls.pyx:47-59): permeability[E][3][3] row-major and diff_mag[E] (may be NULL for IDW / LS),
+ * neumann_flag[P] (the points_data row, cast to integer like `.astype(int)`), neumann_val[P]
+ * (may be NULL for IDW / LS).  Host pointers; uploaded to the grid's device. */
+int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_mag,
+                   const double *neumann_flag, const double *neumann_val);
+
+/* ---- the hot path -------------------------------------------------------------------------
+ * Replaces supported_methods[method](grid, ..., target_points, weights, neumann_ws)
+ * (interpolator.pyx:657-665 -> idw.pyx:14-84, ls.pyx:21-135, gls.pyx:38-474).
+ *
+ * Output layout: instead of the dense weights[n_target][MX_ELEMENTS_PER_POINT] table, weight j of
+ * node p is written to csr_data[esup_ptr[p] + j] -- exactly the position the reference's COO fill
+ * reads it into (interpolator.pyx:612-618), with column esup[esup_ptr[p] + j].  neumann_ws has
+ * n_points entries.  Entries of nodes that the method skips (Dirichlet boundary nodes,
+ * idw.pyx:62-63) and of nodes outside `targets` are 0.
+ *
+ * targets: int64 node ids (host pointer) or NULL for all nodes.  add_neumann != 0 applies
+ * `data[j] = weights + neumann_ws[row]` of interpolator.pyx:618 in the same kernel.
+ * dev_csr_data [nnz_esup] and dev_neumann_ws [n_points] are DEVICE pointers; the launch is
+ * asynchronous on `stream`. */
+int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t n_targets,
+                       int add_neumann, double *dev_csr_data, double *dev_neumann_ws, void *stream);
+
+/* Same, with host outputs (allocates scratch on the device, synchronises, copies back). */
+int nin_weights_host(nin_grid *g, int method, const int64_t *targets, int64_t n_targets,
+                     int add_neumann, double *csr_data, double *neumann_ws);
+
+/* Device-side finish of interpolator.pyx:622-624 (csr_matrix + eliminate_zeros): compacts the
+ * esup-shaped (indptr = esup_ptr, indices = esup, data) triplet, dropping exact zeros.
+ * Host outputs: indptr[n_points+1] (int32, what scipy picks for these sizes), indices / data sized
+ * by the caller to nnz_esup; *nnz_out receives the surviving count. */
+int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indptr, int32_t *indices,
+                         double *data, int64_t *nnz_out, void *stream);
+
+/* Algorithmic HBM bytes one nin_weights call moves for `method` over all nodes (DESIGN.md formula,
+ * SURVEY 8d): used by bench.py for the roofline line. */
+int64_t nin_algorithmic_bytes(const nin_grid *g, int method);
+
+/* Name of the dominant kernel of `method` as it appears in rocprofv3 traces. */
+const char *nin_kernel_name(int method);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NINPOL_AMD_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of libninpol_amd.so (the C ABI in include/ninpol_amd.h).
+
+There is no fallback: if the shared object is missing or does not load, importing the product
+path fails loudly.  (`python -m ninpol_amd.build` / `__graft_entry__.build()` produce it.)
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libninpol_amd.so")
+
+NIN_OK = 0
+NIN_EINVAL, NIN_ENOMEM, NIN_EHIP, NIN_ENODEVICE, NIN_ERANGE, NIN_ESTATE = -1, -2, -3, -4, -5, -6
+METHOD_ID = {"gls": 0, "idw": 1, "ls": 2}
+
+EXPORTS = (
+    "nin_last_error", "nin_version", "nin_grid_create", "nin_grid_destroy", "nin_grid_scalar",
+    "nin_grid_array_info", "nin_grid_array_copy", "nin_device_count", "nin_grid_to_device", "nin_grid_device",
+    "nin_fields_set", "nin_weights_device", "nin_weights_host", "nin_csr_compact_host",
+    "nin_algorithmic_bytes", "nin_kernel_name",
+)
+
+_lib = None
+
+
+class NinpolError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libninpol_amd error {code}: {text}")
+        self.code = code
+        self.text = text
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m ninpol_amd.build` "
+                          "(there is no CPU fallback for the weight kernels)")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32, cp, dp = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p
+    L.nin_last_error.restype = cp
+    L.nin_version.restype = cp
+    L.nin_grid_create.argtypes = [i64, i64, i64] + [vp] * 9 + [i32, i32, i32, ctypes.POINTER(vp)]
+    L.nin_grid_destroy.argtypes = [vp]
+    L.nin_grid_destroy.restype = None
+    L.nin_grid_scalar.argtypes = [vp, cp]
+    L.nin_grid_scalar.restype = i64
+    L.nin_grid_array_info.argtypes = [vp, cp, ctypes.POINTER(i64), ctypes.POINTER(i32)]
+    L.nin_grid_array_copy.argtypes = [vp, cp, vp, i64]
+    L.nin_device_count.argtypes = [ctypes.POINTER(i32)]
+    L.nin_grid_to_device.argtypes = [vp, i32]
+    L.nin_grid_device.argtypes = [vp]
+    L.nin_fields_set.argtypes = [vp, dp, dp, dp, dp]
+    L.nin_weights_device.argtypes = [vp, i32, vp, i64, i32, vp, vp, vp]
+    L.nin_weights_host.argtypes = [vp, i32, vp, i64, i32, vp, vp]
+    L.nin_csr_compact_host.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(i64), vp]
+    L.nin_algorithmic_bytes.argtypes = [vp, i32]
+    L.nin_algorithmic_bytes.restype = i64
+    L.nin_kernel_name.argtypes = [i32]
+    L.nin_kernel_name.restype = cp
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != NIN_OK:
+        raise NinpolError(rc, load().nin_last_error().decode())
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = load().nin_device_count(ctypes.byref(n))
+    return n.value if rc == NIN_OK else 0

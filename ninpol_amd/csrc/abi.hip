@@ -1,0 +1,487 @@
+// abi.hip -- the extern "C" surface declared in include/ninpol_amd.h.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ninpol_amd.h"
+#include "device_grid.hpp"
+#include "grid_host.hpp"
+#include "launch.hpp"
+
+using namespace nin;
+
+struct nin_grid {
+    HostGrid h;
+    DeviceGrid d;
+    std::vector<uint8_t> node_class;  // GLS size class of every node (host copy, for target subsets)
+    int coords_dim = 3;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+template <class T>
+int dev_alloc(DeviceGrid &d, T **ptr, size_t count) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(NIN_ENOMEM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+    d.allocs.push_back(p);
+    *ptr = static_cast<T *>(p);
+    return 0;
+}
+
+template <class T>
+int dev_upload(DeviceGrid &d, const T **ptr, const std::vector<T> &src) {
+    T *p = nullptr;
+    int rc = dev_alloc(d, &p, src.size());
+    if (rc) return rc;
+    if (!src.empty()) HIP_TRY(hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    *ptr = p;
+    return 0;
+}
+
+void dev_free_all(DeviceGrid &d) {
+    if (d.device >= 0) (void)hipSetDevice(d.device);
+    for (void *p : d.allocs) (void)hipFree(p);
+    d.allocs.clear();
+    d = DeviceGrid{};
+}
+
+// LDS bytes per wave a node's system may take in class c (last class = global-memory scratch)
+const int32_t kClassBudget[kGlsClasses] = {9216, 16384, 32768, 65536, 159744, 0};
+
+struct ArrayRef {
+    int dtype;      // NIN_I64 / NIN_F64
+    int64_t count;
+    int kind;       // source element type: 0 int32, 1 int64, 2 uint8, 3 int8, 4 double, 5 float
+    const void *ptr;
+};
+
+bool lookup_array(nin_grid *g, const std::string &name, ArrayRef *r) {
+    HostGrid &h = g->h;
+    auto I32 = [&](const std::vector<int32_t> &v) { *r = {NIN_I64, (int64_t)v.size(), 0, v.data()}; return true; };
+    auto I64 = [&](const std::vector<int64_t> &v) { *r = {NIN_I64, (int64_t)v.size(), 1, v.data()}; return true; };
+    auto U8 = [&](const std::vector<uint8_t> &v) { *r = {NIN_I64, (int64_t)v.size(), 2, v.data()}; return true; };
+    auto F64 = [&](const std::vector<double> &v) { *r = {NIN_F64, (int64_t)v.size(), 4, v.data()}; return true; };
+    if (name == "esup") return I32(h.esup);
+    if (name == "esup_ptr") return I64(h.esup_ptr);
+    if (name == "fsup") return I32(h.fsup);
+    if (name == "fsup_ptr") return I64(h.fsup_ptr);
+    if (name == "esuf") return I32(h.esuf);
+    if (name == "esuf_ptr") return I64(h.esuf_ptr);
+    if (name == "esuel") return I32(h.esuel);
+    if (name == "infael") return I32(h.infael);
+    if (name == "inpofa") return I32(h.inpofa);
+    if (name == "inpoel") return I32(h.inpoel);
+    if (name == "boundary_faces") return U8(h.boundary_faces);
+    if (name == "boundary_points") return U8(h.boundary_points);
+    if (name == "element_types") { *r = {NIN_I64, (int64_t)h.etype.size(), 3, h.etype.data()}; return true; }
+    if (name == "psup" || name == "psup_ptr") {
+        h.build_psup();
+        return name == "psup" ? I32(h.psup) : I64(h.psup_ptr);
+    }
+    if (name == "inedel" || name == "inpoed") {
+        if (!h.build_edges) { *r = {NIN_I64, 0, 0, nullptr}; return true; }  // empty, like the reference's (0,0) arrays
+        h.build_inedel();
+        return name == "inedel" ? I32(h.inedel) : I32(h.inpoed);
+    }
+    if (name == "point_coords") return F64(h.coords);
+    if (name == "centroids") return F64(h.centroids);
+    if (name == "faces_centers") return F64(h.faces_centers);
+    if (name == "faces_areas") return F64(h.faces_areas);
+    if (name == "normal_faces") { *r = {NIN_F64, (int64_t)h.normal_faces.size(), 5, h.normal_faces.data()}; return true; }
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *nin_last_error(void) { return g_err.c_str(); }
+const char *nin_version(void) { return "ninpol_amd 0.1 (gfx950)"; }
+
+int nin_grid_create(int64_t dim, int64_t n_elems, int64_t n_points, const int64_t *npoel, const int64_t *nfael,
+                    const int64_t *lnofa, const int64_t *lpofa, const int64_t *nedel, const int64_t *lpoed,
+                    const int64_t *connectivity, const int64_t *element_types, const double *coords, int coords_dim,
+                    int build_edges, int num_threads, nin_grid **out) {
+    if (!out) return fail(NIN_EINVAL, "out is NULL");
+    *out = nullptr;
+    // the three checks of grid.pyx:55-60 (the Python layer turns them into the reference's ValueErrors)
+    if (dim < 1) return fail(NIN_EINVAL, "The number of dimensions must be greater than 0.");
+    if (n_elems < 1) return fail(NIN_EINVAL, "The number of elements must be greater than 0.");
+    if (n_points < 1) return fail(NIN_EINVAL, "The number of points must be greater than 0.");
+    if (!npoel || !nfael || !lnofa || !lpofa || !nedel || !lpoed || !connectivity || !element_types || !coords)
+        return fail(NIN_EINVAL, "NULL table or array");
+    if (coords_dim < 1 || coords_dim > 3) return fail(NIN_EINVAL, "coords_dim must be 1..3");
+    if (n_elems * 8 >= INT32_MAX || n_points >= INT32_MAX) return fail(NIN_ERANGE, "mesh too large for the int32 layout");
+    nin_grid *g = new (std::nothrow) nin_grid();
+    if (!g) return fail(NIN_ENOMEM, "out of host memory");
+    HostGrid &h = g->h;
+    h.dim = dim; h.n_elems = n_elems; h.n_points = n_points;
+    h.build_edges = build_edges; h.num_threads = num_threads;
+    g->coords_dim = coords_dim;
+    for (int t = 0; t < kNumElementTypes; ++t) {
+        h.npoel[t] = (int32_t)npoel[t]; h.nfael[t] = (int32_t)nfael[t]; h.nedel[t] = (int32_t)nedel[t];
+        for (int f = 0; f < kMaxFacesPerElement; ++f) {
+            h.lnofa[t][f] = (int32_t)lnofa[t * kMaxFacesPerElement + f];
+            for (int k = 0; k < kMaxPointsPerFace; ++k)
+                h.lpofa[t][f][k] = (int32_t)lpofa[(t * kMaxFacesPerElement + f) * kMaxPointsPerFace + k];
+        }
+        for (int e = 0; e < kMaxEdgesPerElement; ++e)
+            for (int k = 0; k < 2; ++k) h.lpoed[t][e][k] = (int32_t)lpoed[(t * kMaxEdgesPerElement + e) * 2 + k];
+    }
+    int rc;
+    try {
+        rc = h.build(connectivity, element_types, coords, coords_dim);
+    } catch (const std::bad_alloc &) {
+        delete g;
+        return fail(NIN_ENOMEM, "out of host memory while building the grid");
+    }
+    if (rc == -5) { delete g; return fail(NIN_ERANGE, "a connectivity count does not fit int32"); }
+    if (rc) { delete g; return fail(NIN_EINVAL, "connectivity references a point outside [0, n_points) or an unknown element type"); }
+    *out = g;
+    return NIN_OK;
+}
+
+void nin_grid_destroy(nin_grid *g) {
+    if (!g) return;
+    dev_free_all(g->d);
+    delete g;
+}
+
+int64_t nin_grid_scalar(const nin_grid *g, const char *name) {
+    if (!g || !name) return -1;
+    const HostGrid &h = g->h;
+    const std::string n(name);
+    if (n == "dim") return h.dim;
+    if (n == "n_elems") return h.n_elems;
+    if (n == "n_points") return h.n_points;
+    if (n == "n_faces") return h.n_faces;
+    if (n == "n_edges") { if (h.build_edges) const_cast<HostGrid &>(h).build_inedel(); return h.n_edges; }
+    if (n == "MX_ELEMENTS_PER_POINT") return h.mx_elems_per_point;
+    if (n == "MX_POINTS_PER_POINT") { const_cast<HostGrid &>(h).build_psup(); return h.mx_points_per_point; }
+    if (n == "MX_ELEMENTS_PER_FACE") return h.mx_elems_per_face;
+    if (n == "MX_FACES_PER_POINT") return h.mx_faces_per_point;
+    if (n == "coords_dim") return g->coords_dim;
+    if (n == "nnz_esup") return (int64_t)h.esup.size();
+    if (n == "nnz_fsup") return (int64_t)h.fsup.size();
+    return -1;
+}
+
+int nin_grid_array_info(nin_grid *g, const char *name, int64_t *count, int *dtype) {
+    if (!g || !name || !count || !dtype) return fail(NIN_EINVAL, "NULL argument");
+    ArrayRef r;
+    if (!lookup_array(g, name, &r)) return fail(NIN_EINVAL, "unknown grid array '%s'", name);
+    *count = r.count;
+    *dtype = r.dtype;
+    return NIN_OK;
+}
+
+int nin_grid_array_copy(nin_grid *g, const char *name, void *dst, int64_t count) {
+    if (!g || !name || (!dst && count)) return fail(NIN_EINVAL, "NULL argument");
+    ArrayRef r;
+    if (!lookup_array(g, name, &r)) return fail(NIN_EINVAL, "unknown grid array '%s'", name);
+    if (count != r.count) return fail(NIN_EINVAL, "array '%s' has %lld elements, caller gave room for %lld", name, (long long)r.count, (long long)count);
+    const int64_t n = r.count;
+    switch (r.kind) {
+        case 0: { auto s = (const int32_t *)r.ptr; auto d = (int64_t *)dst;
+#pragma omp parallel for schedule(static)
+                  for (int64_t i = 0; i < n; ++i) d[i] = s[i]; } break;
+        case 1: if (n) memcpy(dst, r.ptr, (size_t)n * 8); break;
+        case 2: { auto s = (const uint8_t *)r.ptr; auto d = (int64_t *)dst; for (int64_t i = 0; i < n; ++i) d[i] = s[i]; } break;
+        case 3: { auto s = (const int8_t *)r.ptr; auto d = (int64_t *)dst; for (int64_t i = 0; i < n; ++i) d[i] = s[i]; } break;
+        case 4: if (n) memcpy(dst, r.ptr, (size_t)n * 8); break;
+        case 5: { auto s = (const float *)r.ptr; auto d = (double *)dst; for (int64_t i = 0; i < n; ++i) d[i] = (double)s[i]; } break;
+    }
+    return NIN_OK;
+}
+
+int nin_device_count(int *count) {
+    if (!count) return fail(NIN_EINVAL, "NULL argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; return fail(NIN_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = c;
+    return NIN_OK;
+}
+
+int nin_grid_device(const nin_grid *g) { return g ? g->d.device : -1; }
+
+int nin_grid_to_device(nin_grid *g, int device) {
+    if (!g) return fail(NIN_EINVAL, "NULL grid");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(NIN_ENODEVICE, "no HIP device visible: libninpol_amd has no CPU fallback for the weight kernels");
+    if (device < 0 || device >= ndev) return fail(NIN_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    dev_free_all(g->d);
+    HIP_TRY(hipSetDevice(device));
+    HostGrid &h = g->h;
+    DeviceGrid &d = g->d;
+    d.device = device;
+    const int64_t P = h.n_points, E = h.n_elems, F = h.n_faces;
+    d.nnz_e = (int64_t)h.esup.size();
+    d.nnz_f = (int64_t)h.fsup.size();
+    GridView &v = d.v;
+    v.n_points = (int32_t)P; v.n_elems = (int32_t)E; v.n_faces = (int32_t)F; v.dim = (int32_t)h.dim;
+    int rc;
+    {
+        std::vector<int32_t> p32((size_t)P + 1);
+        for (int64_t i = 0; i <= P; ++i) p32[i] = (int32_t)h.esup_ptr[i];
+        if ((rc = dev_upload(d, &v.esup_ptr, p32))) return rc;
+        for (int64_t i = 0; i <= P; ++i) p32[i] = (int32_t)h.fsup_ptr[i];
+        if ((rc = dev_upload(d, &v.fsup_ptr, p32))) return rc;
+    }
+    if ((rc = dev_upload(d, &v.esup, h.esup))) return rc;
+    if ((rc = dev_upload(d, &v.fsup, h.fsup))) return rc;
+    if ((rc = dev_upload(d, &v.coords, h.coords))) return rc;
+    if ((rc = dev_upload(d, &v.centroids, h.centroids))) return rc;
+    if ((rc = dev_upload(d, &v.face_center, h.faces_centers))) return rc;
+    if ((rc = dev_upload(d, &v.face_normal, h.normal_faces))) return rc;
+    {
+        std::vector<int32_t> fc((size_t)F * 2);
+#pragma omp parallel for schedule(static)
+        for (int64_t f = 0; f < F; ++f) {
+            const int64_t b = h.esuf_ptr[f], n = h.esuf_ptr[f + 1] - b;
+            fc[2 * f] = h.esuf[b];
+            fc[2 * f + 1] = n > 1 ? h.esuf[b + 1] : -1;
+        }
+        if ((rc = dev_upload(d, &v.face_cells, fc))) return rc;
+    }
+    {   // flags start as "boundary only"; nin_fields_set adds the Neumann bit
+        uint8_t *fl = nullptr;
+        if ((rc = dev_alloc(d, &fl, (size_t)P))) return rc;
+        HIP_TRY(hipMemcpy(fl, h.boundary_points.data(), (size_t)P, hipMemcpyHostToDevice));
+        v.flags = fl;
+        double *perm = nullptr, *dm = nullptr;
+        if ((rc = dev_alloc(d, &perm, (size_t)E * 9))) return rc;
+        if ((rc = dev_alloc(d, &dm, (size_t)E))) return rc;
+        v.perm = perm; v.diff_mag = dm;
+    }
+    // ---- GLS launch plan: bin nodes by the size of their least-squares system -----------------------
+    g->node_class.assign((size_t)P, 0);
+    std::vector<std::vector<int32_t>> lists(kGlsClasses);
+    int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0};
+    for (int64_t p = 0; p < P; ++p) {
+        const int64_t ne = h.esup_ptr[p + 1] - h.esup_ptr[p], nf = h.fsup_ptr[p + 1] - h.fsup_ptr[p];
+        int64_t nbf = 0;
+        for (int64_t q = h.fsup_ptr[p]; q < h.fsup_ptr[p + 1]; ++q) nbf += h.boundary_faces[h.fsup[q]];
+        const int64_t m = ne + 3 * (nf - nbf) + nbf, n = 3 * ne + 1;
+        const int64_t doubles = ((ne + 1) >> 1) + n + m * n;
+        const int64_t bytes = ((doubles * 8 + 15) / 16) * 16;
+        int c = kGlsClasses - 1;
+        for (int k = 0; k < kGlsClasses - 1; ++k)
+            if (bytes <= kClassBudget[k]) { c = k; break; }
+        g->node_class[p] = (uint8_t)c;
+        lists[c].push_back((int32_t)p);
+        need_max[c] = std::max(need_max[c], bytes);
+        rows_max[c] = std::max(rows_max[c], m);
+    }
+    for (int c = 0; c < kGlsClasses; ++c) {
+        auto &k = d.gls[c];
+        k.count = (int32_t)lists[c].size();
+        k.lds_bytes = c == kGlsClasses - 1 ? 0 : (int32_t)need_max[c];
+        k.rows_per_lane = (int32_t)std::max<int64_t>(1, (rows_max[c] + 63) / 64);
+        k.max_rows = (int32_t)rows_max[c];
+        const int32_t *lp = nullptr;
+        if (k.count && (rc = dev_upload(d, &lp, lists[c]))) return rc;
+        k.nodes = const_cast<int32_t *>(lp);
+    }
+    if (d.gls[kGlsClasses - 1].count) {
+        d.gls_scratch_slots = 1024;
+        d.gls_scratch_stride = need_max[kGlsClasses - 1] / 8;
+        if ((rc = dev_alloc(d, &d.gls_scratch, (size_t)d.gls_scratch_slots * d.gls_scratch_stride))) return rc;
+    }
+    // a single class holding every node in order needs no list: the kernel walks 0..P-1 directly
+    for (int c = 0; c < kGlsClasses; ++c)
+        if (d.gls[c].count == P) d.gls[c].nodes = nullptr;
+    HIP_TRY(hipDeviceSynchronize());
+    return NIN_OK;
+}
+
+int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_mag, const double *neumann_flag,
+                   const double *neumann_val) {
+    (void)neumann_val;  // only feeds the Neumann RHS column, which gls.pyx:464-472 never reads back
+    if (!g) return fail(NIN_EINVAL, "NULL grid");
+    if (g->d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
+    if (!neumann_flag) return fail(NIN_EINVAL, "neumann_flag is required by every method");
+    HIP_TRY(hipSetDevice(g->d.device));
+    HostGrid &h = g->h;
+    DeviceGrid &d = g->d;
+    const int64_t P = h.n_points, E = h.n_elems;
+    std::vector<uint8_t> fl((size_t)P);
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < P; ++p) {
+        const long long as_int = (long long)neumann_flag[p];  // `.astype(int)` (idw.pyx:28): truncation
+        fl[p] = (uint8_t)((h.boundary_points[p] ? 1 : 0) | (as_int != 0 ? 2 : 0));
+    }
+    HIP_TRY(hipMemcpy(const_cast<uint8_t *>(d.v.flags), fl.data(), (size_t)P, hipMemcpyHostToDevice));
+    d.have_perm = permeability && diff_mag;
+    if (d.have_perm) {
+        HIP_TRY(hipMemcpy(const_cast<double *>(d.v.perm), permeability, (size_t)E * 9 * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(const_cast<double *>(d.v.diff_mag), diff_mag, (size_t)E * 8, hipMemcpyHostToDevice));
+    }
+    d.fields_set = true;
+    return NIN_OK;
+}
+
+int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t n_targets, int add_neumann,
+                       double *dev_csr_data, double *dev_neumann_ws, void *stream_) {
+    if (!g || !dev_csr_data || !dev_neumann_ws) return fail(NIN_EINVAL, "NULL argument");
+    DeviceGrid &d = g->d;
+    if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
+    if (!d.fields_set) return fail(NIN_ESTATE, "nin_fields_set has not been called");
+    if (method != NIN_METHOD_GLS && method != NIN_METHOD_IDW && method != NIN_METHOD_LS)
+        return fail(NIN_EINVAL, "unknown method %d", method);
+    if (method == NIN_METHOD_GLS && !d.have_perm) return fail(NIN_ESTATE, "GLS needs permeability and diff_mag");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(d.device));
+    const int64_t P = g->h.n_points;
+    const bool all = targets == nullptr;
+    if (!all && n_targets < 0) return fail(NIN_EINVAL, "negative n_targets");
+    int rc = 0;
+    if (all) {
+        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, nullptr, (int32_t)P, dev_csr_data, dev_neumann_ws, stream);
+        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, dev_csr_data, dev_neumann_ws, stream);
+        else {
+            for (int c = 0; c < kGlsClasses && !rc; ++c) {
+                auto &k = d.gls[c];
+                rc = launch_gls_class(d.v, k.nodes, k.count, k.lds_bytes, k.rows_per_lane, add_neumann, dev_csr_data,
+                                      dev_neumann_ws, d.gls_scratch, d.gls_scratch_stride, d.gls_scratch_slots, stream);
+            }
+        }
+        if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return NIN_OK;
+    }
+    // explicit target list: outputs of every other node are zero
+    for (int64_t i = 0; i < n_targets; ++i)
+        if (targets[i] < 0 || targets[i] >= P) return fail(NIN_EINVAL, "target %lld out of range", (long long)targets[i]);
+    HIP_TRY(hipMemsetAsync(dev_csr_data, 0, (size_t)d.nnz_e * 8, stream));
+    HIP_TRY(hipMemsetAsync(dev_neumann_ws, 0, (size_t)P * 8, stream));
+    if (n_targets == 0) return NIN_OK;
+    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses : 1);
+    for (int64_t i = 0; i < n_targets; ++i) {
+        const int c = method == NIN_METHOD_GLS ? g->node_class[targets[i]] : 0;
+        lists[c].push_back((int32_t)targets[i]);
+    }
+    for (size_t c = 0; c < lists.size() && !rc; ++c) {
+        if (lists[c].empty()) continue;
+        int32_t *dl = nullptr;
+        HIP_TRY(hipMallocAsync((void **)&dl, lists[c].size() * 4, stream));
+        HIP_TRY(hipMemcpyAsync(dl, lists[c].data(), lists[c].size() * 4, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));  // the pageable source vector dies with this scope
+        const int32_t cnt = (int32_t)lists[c].size();
+        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, dev_csr_data, dev_neumann_ws, stream);
+        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, dev_csr_data, dev_neumann_ws, stream);
+        else rc = launch_gls_class(d.v, dl, cnt, d.gls[c].lds_bytes, d.gls[c].rows_per_lane, add_neumann, dev_csr_data,
+                                   dev_neumann_ws, d.gls_scratch, d.gls_scratch_stride, d.gls_scratch_slots, stream);
+        HIP_TRY(hipFreeAsync(dl, stream));
+    }
+    if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return NIN_OK;
+}
+
+int nin_weights_host(nin_grid *g, int method, const int64_t *targets, int64_t n_targets, int add_neumann,
+                     double *csr_data, double *neumann_ws) {
+    if (!g || !csr_data || !neumann_ws) return fail(NIN_EINVAL, "NULL argument");
+    DeviceGrid &d = g->d;
+    if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
+    HIP_TRY(hipSetDevice(d.device));
+    const size_t nb = (size_t)std::max<int64_t>(d.nnz_e, 1) * 8, pb = (size_t)g->h.n_points * 8;
+    double *dd = nullptr, *dn = nullptr;
+    HIP_TRY(hipMalloc((void **)&dd, nb));
+    hipError_t e = hipMalloc((void **)&dn, pb);
+    if (e != hipSuccess) { (void)hipFree(dd); return fail(NIN_ENOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    int rc = nin_weights_device(g, method, targets, n_targets, add_neumann, dd, dn, nullptr);
+    if (!rc) {
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(csr_data, dd, (size_t)d.nnz_e * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(neumann_ws, dn, pb, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(NIN_EHIP, "weights kernel / copy back: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dd);
+    (void)hipFree(dn);
+    return rc;
+}
+
+int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indptr, int32_t *indices, double *data,
+                         int64_t *nnz_out, void *stream_) {
+    if (!g || !dev_csr_data || !indptr || !nnz_out) return fail(NIN_EINVAL, "NULL argument");
+    DeviceGrid &d = g->d;
+    if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(d.device));
+    const int64_t P = g->h.n_points;
+    int32_t *cnt = nullptr, *ptr = nullptr, *di = nullptr;
+    double *dv = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int rc = NIN_OK;
+    auto cleanup = [&]() { (void)hipFree(cnt); (void)hipFree(ptr); (void)hipFree(di); (void)hipFree(dv); (void)hipFree(tmp); };
+#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    TRY_C(hipMalloc((void **)&cnt, (size_t)(P + 1) * 4));
+    TRY_C(hipMalloc((void **)&ptr, (size_t)(P + 1) * 4));
+    TRY_C(hipMemsetAsync(cnt, 0, (size_t)(P + 1) * 4, stream));
+    if ((rc = launch_row_nnz(d.v, dev_csr_data, cnt, stream))) { cleanup(); return fail(rc, "launch failed"); }
+    TRY_C(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, ptr, (int)(P + 1), stream));
+    TRY_C(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    TRY_C(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, ptr, (int)(P + 1), stream));
+    TRY_C(hipMemcpyAsync(indptr, ptr, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, stream));
+    TRY_C(hipStreamSynchronize(stream));
+    const int64_t nnz = indptr[P];
+    *nnz_out = nnz;
+    if (nnz > 0 && indices && data) {
+        TRY_C(hipMalloc((void **)&di, (size_t)nnz * 4));
+        TRY_C(hipMalloc((void **)&dv, (size_t)nnz * 8));
+        if ((rc = launch_compact(d.v, dev_csr_data, ptr, di, dv, stream))) { cleanup(); return fail(rc, "launch failed"); }
+        TRY_C(hipMemcpyAsync(indices, di, (size_t)nnz * 4, hipMemcpyDeviceToHost, stream));
+        TRY_C(hipMemcpyAsync(data, dv, (size_t)nnz * 8, hipMemcpyDeviceToHost, stream));
+        TRY_C(hipStreamSynchronize(stream));
+    }
+#undef TRY_C
+    cleanup();
+    return NIN_OK;
+}
+
+int64_t nin_algorithmic_bytes(const nin_grid *g, int method) {
+    if (!g) return -1;
+    // SURVEY 8(d), canonical device layout s_i = 4:
+    //   B_idw/ls = 4(P+1) + 4 nnz_esup + 24P + 24E + 2P + (8+4) nnz_out + 8P          (nnz_out = nnz_esup)
+    //   B_gls    = B_idw/ls + 4(P+1) + 4 nnz_fsup + F (2*4 + 1 + 24 + 24) + E (72+8) + 8P
+    const int64_t P = g->h.n_points, E = g->h.n_elems, F = g->h.n_faces;
+    const int64_t nze = (int64_t)g->h.esup.size(), nzf = (int64_t)g->h.fsup.size();
+    int64_t b = 4 * (P + 1) + 4 * nze + 24 * P + 24 * E + 2 * P + 12 * nze + 8 * P;
+    if (method == NIN_METHOD_GLS) b += 4 * (P + 1) + 4 * nzf + F * 57 + E * 80 + 8 * P;
+    return b;
+}
+
+const char *nin_kernel_name(int method) {
+    if (method == NIN_METHOD_IDW) return "nin_idw_kernel";
+    if (method == NIN_METHOD_LS) return "nin_ls_kernel";
+    return kernel_name_gls();
+}
+
+}  // extern "C"

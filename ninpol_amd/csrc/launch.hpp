@@ -1,0 +1,31 @@
+// launch.hpp -- kernel launchers shared between the .hip translation units and the C ABI (internal)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_grid.hpp"
+
+namespace nin {
+
+// all return 0 or a negative NIN_E* code; launches are asynchronous on `stream`
+int launch_idw(const GridView &g, const int32_t *targets, int32_t n_targets, double *out, double *nws,
+               hipStream_t stream);
+int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, double *out, double *nws,
+              hipStream_t stream);
+// one GLS size class: `nodes` lists the class members (device), lds_bytes is per wave
+int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes,
+                     int32_t rows_per_lane, int add_neumann, double *out, double *nws,
+                     double *scratch, int64_t scratch_stride, int32_t scratch_slots, hipStream_t stream);
+// out[j] += nws[row(j)] for IDW / LS is a no-op (their neumann_ws is 0): nothing to launch.
+
+// CSR finish (interpolator.pyx:622-624): count non-zeros per row, scan, compact
+int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipStream_t stream);
+int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr, int32_t *indices,
+                   double *vals, hipStream_t stream);
+
+const char *kernel_name_idw();
+const char *kernel_name_ls();
+const char *kernel_name_gls();
+
+}  // namespace nin

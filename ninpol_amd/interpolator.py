@@ -1,0 +1,307 @@
+"""`Interpolator`: the drop-in boundary.  Same class surface as the reference's
+`ninpol.Interpolator` (ninpol/_interpolator/interpolator.pyx, interpolator.pxd:27-58) -- constructor,
+`load_mesh`, `interpolate`, `load_face_data`, `get_data`, `get_dict`, `supported_methods`, `grid` --
+with the work done by libninpol_amd.so: the grid is built by the native host builder, pushed to HBM
+once, and `interpolate()` runs the HIP kernels.  Python here is argument checking and table packing.
+
+What is deliberately not reproduced (out of scope): the pickle grid cache
+(interpolator.pyx:93-166,244-252) and the Logger class (plain prints behind `logging=`).
+"""
+import ctypes
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from . import topology as T
+from .grid import Grid
+
+DTYPE_I = np.int64
+DTYPE_F = np.float64
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class _MethodPlugin:
+    """The reference's method-plugin convention (interpolator.pyx:631-665 docstring + call):
+
+        prepare(grid, cells_data, points_data, faces_data, variable_to_index, variable,
+                target_points, weights[out, pre-zeroed, (n_target, MX_ELEMENTS_PER_POINT)],
+                neumann_ws[out, pre-zeroed])
+
+    replacing IDWInterpolation.prepare (idw.pyx:14-30), LSInterpolation.prepare (ls.pyx:21-31) and
+    GLSInterpolation.prepare (gls.pyx:38-72).  Caller owns every buffer; nothing is retained."""
+
+    def __init__(self, name):
+        self.name = name
+        self.logging = False
+
+    def prepare(self, grid, cells_data, points_data, faces_data, variable_to_index, variable, target_points,
+                weights, neumann_ws):
+        csr, nws = _run_weights(grid, self.name, cells_data, points_data, variable_to_index, variable,
+                                target_points, add_neumann=False)
+        P = grid.n_points
+        targets = np.asarray(target_points, dtype=DTYPE_I)
+        ptr = grid.esup_ptr
+        full = len(targets) == P and np.array_equal(targets, np.arange(P))
+        rows_src = np.arange(P) if full else targets
+        cnt = (ptr[1:] - ptr[:-1])[rows_src]
+        dst_rows = np.repeat(np.arange(len(rows_src)), cnt)
+        cols = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        src = np.repeat(ptr[:-1][rows_src], cnt) + cols
+        w = np.asarray(weights)
+        w[dst_rows, cols] = csr[src]
+        np.asarray(neumann_ws)[:len(rows_src)] = nws[rows_src]
+
+    __call__ = prepare
+
+
+def _run_weights(grid, method, cells_data, points_data, variable_to_index, variable, target_points, add_neumann):
+    """Look the field rows up exactly as the plugins do (idw.pyx:27, ls.pyx:27, gls.pyx:47-59; a missing
+    name is a KeyError there too), hand them to the device and run the kernel."""
+    L = _lib.load()
+    if grid.device < 0:
+        grid.to_device(0)
+    P, E = grid.n_points, grid.n_elems
+    v2i = variable_to_index
+    flag = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_flag_" + variable]][:P], dtype=DTYPE_F)
+    perm = dmag = nval = None
+    if method == "gls":
+        cd = np.asarray(cells_data)
+        perm = np.ascontiguousarray(cd[v2i["cells"]["permeability"]][:E * 9], dtype=DTYPE_F)
+        dmag = np.ascontiguousarray(cd[v2i["cells"]["diff_mag"]][:E], dtype=DTYPE_F)
+        nval = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_" + variable]][:P], dtype=DTYPE_F)
+    _lib.check(L.nin_fields_set(grid._h, _ptr(perm), _ptr(dmag), _ptr(flag), _ptr(nval)))
+    targets = np.ascontiguousarray(target_points, dtype=DTYPE_I)
+    full = len(targets) == 0 or (len(targets) == P and np.array_equal(targets, np.arange(P)))
+    csr = np.empty(len(grid.esup), dtype=DTYPE_F)
+    nws = np.empty(P, dtype=DTYPE_F)
+    _lib.check(L.nin_weights_host(grid._h, _lib.METHOD_ID[method], None if full else _ptr(targets),
+                                  0 if full else len(targets), int(bool(add_neumann)), _ptr(csr), _ptr(nws)))
+    return csr, nws
+
+
+class Interpolator:
+    def __init__(self, name="interpolator", logging=False, build_edges=False, device=0, num_threads=0):
+        _lib.load()   # fail here, loudly, if the native library is missing
+        self.name = name
+        self.point_ordering = T.POINT_ORDERING           # utils/point_ordering.yaml as data
+        self.is_grid_initialized = False
+        self.build_edges = int(build_edges)
+        self.gls, self.idw, self.ls = _MethodPlugin("gls"), _MethodPlugin("idw"), _MethodPlugin("ls")
+        self.supported_methods = {"gls": self.gls.prepare, "idw": self.idw.prepare, "ls": self.ls.prepare}
+        self.variable_to_index = {"points": {}, "cells": {}, "faces": {}}
+        self.types_per_dimension = {k: list(v) for k, v in T.TYPES_PER_DIMENSION.items()}
+        self.cells_data = np.zeros((1, 1), dtype=DTYPE_F)
+        self.cells_data_dimensions = np.zeros(1, dtype=DTYPE_I)
+        self.points_data = np.zeros((1, 1), dtype=DTYPE_F)
+        self.points_data_dimensions = np.zeros(1, dtype=DTYPE_I)
+        self.faces_data = np.zeros((1, 1), dtype=DTYPE_F)
+        self.faces_data_dimensions = np.zeros(1, dtype=DTYPE_I)
+        self.logging = int(logging)
+        self.device = int(device)
+        self.num_threads = int(num_threads)
+        self.mesh_obj = None
+        self.grid = None
+        self.points_coords = None
+
+    def _log(self, msg, kind="INFO"):
+        if self.logging:
+            print(f"[{kind:<5}] ({time.strftime('%H:%M:%S'):<8}) {msg}")
+
+    def is_cached(self, filename):
+        """The reference's pickle cache (interpolator.pyx:93-111) is not kept: nothing is ever cached."""
+        return None
+
+    # ---- load_mesh, interpolator.pyx:168-252 ----------------------------------------------------
+    def load_mesh(self, filename="", mesh_obj=None):
+        if filename == "" and mesh_obj is None:
+            raise ValueError("Filename for the mesh or meshio.Mesh object must be provided.")
+        if filename != "":
+            try:
+                import meshio
+            except ImportError as e:   # the reference imports meshio at module level
+                raise ImportError("reading a mesh file needs meshio; pass mesh_obj= instead") from e
+            self._log(f"Reading mesh from {filename}")
+            self.mesh_obj = meshio.read(filename)
+        else:
+            self._log("Using mesh object")
+            self.mesh_obj = mesh_obj
+        t0 = time.time()
+        args = self.process_mesh(self.mesh_obj)
+        self.points_coords = np.ascontiguousarray(np.asarray(self.mesh_obj.points).astype(DTYPE_F))
+        self.grid = Grid(*args, coords=self.points_coords, num_threads=self.num_threads)
+        self._log(f"Grid built in {time.time() - t0:.2f} seconds")
+        t0 = time.time()
+        self.variable_to_index = {"points": {}, "cells": {}, "faces": {}}
+        if self.mesh_obj.cell_data:
+            self.load_cell_data()
+        else:
+            self.cells_data = np.zeros((1, 1), dtype=DTYPE_F)
+            self.cells_data_dimensions = np.zeros(1, dtype=DTYPE_I)
+        if self.mesh_obj.point_data:
+            self.load_point_data()
+        else:
+            self.points_data = np.zeros((1, 1), dtype=DTYPE_F)
+            self.points_data_dimensions = np.zeros(1, dtype=DTYPE_I)
+        self._log(f"Data loaded in {time.time() - t0:.2f} seconds")
+        self.is_grid_initialized = True
+        self._log(f"Mesh loaded successfully: {self.grid.n_points} points and {self.grid.n_elems} elements.")
+
+    def process_mesh(self, mesh):
+        """interpolator.pyx:255-369, vectorised: fixed-width -1 padded connectivity + topology tables."""
+        dim = T.mesh_dimension([b.type for b in mesh.cells])
+        npoel, nfael, lnofa, lpofa, nedel, lpoed = T.topology_tables(dim)
+        blocks = [b for b in mesh.cells if b.type in self.types_per_dimension[dim]]
+        n_elems = int(sum(len(b.data) for b in blocks))
+        n_points = int(np.asarray(mesh.points).shape[0])
+        connectivity = -np.ones((max(n_elems, 0), T.MAX_POINTS_PER_ELEMENT), dtype=DTYPE_I)
+        element_types = -np.ones(max(n_elems, 0), dtype=DTYPE_I)
+        at = 0
+        for b in blocks:
+            d = np.asarray(b.data)
+            connectivity[at:at + len(d), :d.shape[1]] = d
+            element_types[at:at + len(d)] = T.ELEMENTS[b.type]["element_type"]
+            at += len(d)
+        return (dim, n_elems, n_points, npoel, nfael, lnofa, lpofa, nedel, lpoed, connectivity, element_types,
+                self.logging, self.build_edges)
+
+    # ---- data tables, interpolator.pyx:372-509 --------------------------------------------------
+    def load_data(self, data_dict, data_type):
+        n_vars = len(data_dict)
+        n = self.grid.n_elems if data_type == "cells" else self.grid.n_points
+        dims = np.zeros(n_vars, dtype=DTYPE_I)
+        max_shape = 1
+        for index, variable in enumerate(data_dict):
+            a = np.asarray(data_dict[variable])
+            cur = a.shape[1] if a.ndim > 1 else 1
+            max_shape = max(max_shape, cur)
+            self.variable_to_index[data_type][variable] = index
+            dims[index] = cur
+        table = np.zeros((n_vars, n * max_shape), dtype=DTYPE_F)
+        for variable in data_dict:
+            self._log(f"Loading {data_type} data for variable '{variable}'")
+            index = self.variable_to_index[data_type][variable]
+            cur = int(dims[index])
+            a = np.asarray(data_dict[variable], dtype=DTYPE_F)
+            if len(a) < n:
+                raise IndexError(f"index {len(a)} is out of bounds for axis 0 with size {len(a)}")
+            if cur == 1:
+                table[index, :n] = a[:n] if a.ndim == 1 else a[:n, 0]
+            else:
+                table[index, :n * cur] = a[:n].reshape(n, -1)[:, :cur].reshape(-1)
+        if data_type == "cells":
+            self.cells_data_dimensions, self.cells_data = dims, table
+        else:
+            self.points_data_dimensions, self.points_data = dims, table
+
+    def load_cell_data(self):
+        dim = self.grid.dim
+        cell_data_dict = self.mesh_obj.cell_data_dict
+        cell_data = {}
+        for variable in cell_data_dict:
+            parts = [np.asarray(cell_data_dict[variable][t]) for t in cell_data_dict[variable]
+                     if t in self.types_per_dimension[dim]]
+            cell_data[variable] = np.concatenate(parts) if parts else np.array([])
+            if variable == "permeability":
+                cell_data["diff_mag"] = self.compute_diffusion_magnitude(cell_data["permeability"])
+        self.load_data(cell_data, "cells")
+
+    def load_point_data(self):
+        self.load_data(self.mesh_obj.point_data, "points")
+
+    def compute_diffusion_magnitude(self, permeability):
+        """interpolator.pyx:501-509 AS COMPILED: `detKs ** (1 / 3)` has two C integer literals and the
+        module is built with cdivision=True (setup.py:100-108), so the exponent is 0 and the value the
+        reference uses is (1 - 3 / tr K)^2.  Only this form reproduces the GLS numbers the reference
+        publishes (tests/test_kat.py)."""
+        Ks = np.reshape(np.asarray(permeability, dtype=DTYPE_F), (len(permeability), 3, 3))
+        det = np.linalg.det(Ks)
+        tr = np.trace(Ks, axis1=1, axis2=2)
+        return (1 - (3 * (det ** 0) / tr)) ** 2
+
+    def load_face_data(self, data_dict, face_connectivity=np.array([[]], dtype=int)):
+        """interpolator.pyx:456-499."""
+        face_to_grid = np.arange(self.grid.n_faces, dtype=DTYPE_I)
+        A = np.ascontiguousarray(face_connectivity)
+        if len(A) > 0 and A.size > 0:
+            B = np.ascontiguousarray(self.grid.inpofa).astype(A.dtype)
+            A_view = A.view([("", A.dtype)] * A.shape[1]).ravel()
+            B_view = B.view([("", B.dtype)] * B.shape[1]).ravel()
+            order = np.argsort(B_view)
+            face_to_grid = order[np.searchsorted(B_view[order], A_view)]
+        self.faces_data = np.zeros((len(data_dict), self.grid.n_faces), dtype=DTYPE_F)
+        self.faces_data_dimensions = np.zeros(len(data_dict), dtype=DTYPE_I)
+        for i, variable in enumerate(data_dict):
+            a = np.asarray(data_dict[variable])
+            self.variable_to_index["faces"][variable] = i
+            self.faces_data_dimensions[i] = a.shape[1] if a.ndim > 1 else 1
+            self.faces_data[i] = a[face_to_grid].astype(DTYPE_F).reshape(self.grid.n_faces, -1)[:, 0]
+
+    def get_dict(self):
+        return {"point_ordering": self.point_ordering, "variable_to_index": self.variable_to_index,
+                "cells_data": np.asarray(self.cells_data), "cells_data_dimensions": np.asarray(self.cells_data_dimensions),
+                "points_data": np.asarray(self.points_data), "points_data_dimensions": np.asarray(self.points_data_dimensions)}
+
+    def get_data(self, data_type, index, variable):
+        if data_type == "cells":
+            if variable not in self.variable_to_index["cells"]:
+                raise ValueError(f"Variable '{variable}' not found in cells data.")
+            return np.asarray(self.cells_data[self.variable_to_index["cells"][variable]])[index]
+        if variable not in self.variable_to_index["points"]:
+            raise ValueError(f"Variable '{variable}' not found in points data.")
+        return np.asarray(self.points_data[self.variable_to_index["points"][variable]])[index]
+
+    # ---- interpolate, interpolator.pyx:549-629 ---------------------------------------------------
+    def interpolate(self, variable, method, target_points=np.array([], dtype=DTYPE_I)):
+        if not self.is_grid_initialized:
+            raise ValueError("Grid not initialized. Please load a mesh first.")
+        if method not in self.supported_methods:
+            raise ValueError(f"Method '{method}' not supported. Supported methods are: "
+                             f"{list(self.supported_methods.keys())}")
+        target_points = np.asarray(target_points, dtype=DTYPE_I)
+        if len(target_points) == 0:
+            target_points = np.arange(self.grid.n_points, dtype=DTYPE_I)
+        if variable not in self.variable_to_index["cells"]:
+            raise ValueError(f"Variable '{variable}' not found in cells data. "
+                             "Point -> Cell interpolation not supported yet.")
+        if self.cells_data_dimensions[self.variable_to_index["cells"][variable]] > 1:
+            raise ValueError(f"Variable '{variable}' has more than one dimension. Vector data not supported yet.")
+        self._log(f"Interpolating variable '{variable}' using method '{method}'")
+        g = self.grid
+        P, E = g.n_points, g.n_elems
+        if g.device < 0:
+            g.to_device(self.device)
+        t0 = time.time()
+        # `data[j] = weights[i, j - esup_ptr[point]] + neumann_ws[i]` (interpolator.pyx:618) is fused
+        # into the kernel (add_neumann); the result arrives already in CSR position.
+        csr, nws = _run_weights(g, method, self.cells_data, self.points_data, self.variable_to_index, variable,
+                                target_points, add_neumann=True)
+        self._log(f"Interpolation done in {time.time() - t0:.2f} seconds")
+        full = len(target_points) == P and np.array_equal(target_points, np.arange(P))
+        idx_t = np.int32 if max(len(g.esup), E, P) < np.iinfo(np.int32).max else np.int64
+        if full:
+            W = sp.csr_matrix((csr, g.esup.astype(idx_t), g.esup_ptr.astype(idx_t)), shape=(P, E))
+        else:
+            # The reference only works for the full node set (its plugins write weights[point] into a
+            # table sized by n_target).  Here a subset returns row i = node target_points[i].
+            ptr = g.esup_ptr
+            cnt = (ptr[1:] - ptr[:-1])[target_points]
+            src = np.repeat(ptr[:-1][target_points], cnt) + (np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+            indptr = np.concatenate([[0], np.cumsum(cnt)]).astype(idx_t)
+            W = sp.csr_matrix((csr[src], g.esup[src].astype(idx_t), indptr), shape=(len(target_points), E))
+            nws = nws[target_points]
+        W.eliminate_zeros()
+        return W, nws
+
+    def prepare_interpolator(self, method, variable, target_points):
+        """interpolator.pyx:631-670: dense (n_target, MX_ELEMENTS_PER_POINT) weights + neumann_ws."""
+        target_points = np.asarray(target_points, dtype=DTYPE_I)
+        weights = np.zeros((len(target_points), self.grid.MX_ELEMENTS_PER_POINT), dtype=DTYPE_F)
+        neumann_ws = np.zeros(len(target_points), dtype=DTYPE_F)
+        self.supported_methods[method](self.grid, self.cells_data, self.points_data, self.faces_data,
+                                       self.variable_to_index, variable, target_points, weights, neumann_ws)
+        return weights, neumann_ws

@@ -1,0 +1,84 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle on the same inputs and
+against the committed golden fixtures.  Run with `-m gpu` on an MI355X.
+
+Bars (north_star): integers bit-exact; float64 weights within 1e-10 relative (row-scaled, util.py).
+IDW and LS are held to a much tighter bar (1e-14 row-relative, NaN rows on the same nodes) since the
+kernels follow the reference's operation order with FMA contraction off."""
+import numpy as np
+import pytest
+
+import util
+from ninpol_amd import mesh as M
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-14
+
+
+def _interp():
+    import ninpol_amd
+    return ninpol_amd.Interpolator()
+
+
+@pytest.mark.parametrize("case", util.GOLDEN_CASES)
+def test_gpu_matches_golden(case):
+    mesh, z = util.load_golden(case)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    util.assert_grid_equal(I.grid, z)
+    for meth in ("idw", "ls", "gls"):
+        w, nw = I.prepare_interpolator(meth, "u", np.arange(I.grid.n_points))
+        tol = util.WEIGHT_RTOL if meth == "gls" else TIGHT
+        assert util.rowscaled_err(w, z[f"{meth}_weights"]) <= tol, meth
+        assert util.rowscaled_err(nw, z[f"{meth}_neumann_ws"]) <= tol, meth
+        W, nws = I.interpolate("u", meth)
+        assert W.shape == (I.grid.n_points, I.grid.n_elems)
+        err = util.csr_rowscaled_err(W, z[f"{meth}_indptr"], z[f"{meth}_indices"], z[f"{meth}_data"])
+        assert err <= tol, (meth, err)
+
+
+def _meshes():
+    yield "hex20_jitter_neu", M.hex_mesh(20, jitter=0.15, seed=0), "ALH", (2, 0.0)
+    yield "hex16_uniform_neu", M.hex_mesh(16), "LIN", (0, 1.0)
+    yield "tet7_jitter", M.tet_mesh(7, jitter=0.1, seed=1), "ALH", (1, 0.0)
+    yield "wedge8", M.wedge_mesh(8, 6, 5, jitter=0.05, seed=2), "ALH", (2, 1.0)
+    yield "mixed1266", M.mixed_mesh(12, 6, 6, jitter=0.1, seed=3), "ALH", (2, 1.0)
+
+
+@pytest.mark.parametrize("name,mesh,perm,plane", list(_meshes()), ids=[m[0] for m in _meshes()])
+def test_gpu_matches_oracle(oracle_lib, name, mesh, perm, plane):
+    M.attach_fields(mesh, "u", perm=perm, neumann_plane=plane, seed=7)
+    o = oracle_lib.OracleInterpolator("port", threads=8)
+    o.load_mesh(mesh)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    for k in util.GRID_SCALARS:
+        assert getattr(I.grid, k) == getattr(o.grid, k), k
+    for k in util.GRID_ARRAYS:
+        np.testing.assert_array_equal(getattr(I.grid, k), getattr(o.grid, k), err_msg=k)
+    for meth in ("idw", "ls", "gls"):
+        wo, no = o.prepare(meth, "u")
+        w, nw = I.prepare_interpolator(meth, "u", np.arange(I.grid.n_points))
+        tol = util.WEIGHT_RTOL if meth == "gls" else TIGHT
+        assert util.rowscaled_err(w, wo) <= tol, meth
+        assert util.rowscaled_err(nw, no) <= tol, meth
+        Wo, _ = o.interpolate("u", meth)
+        W, _ = I.interpolate("u", meth)
+        assert util.csr_rowscaled_err(W, Wo.indptr, Wo.indices, Wo.data) <= tol, meth
+
+
+def test_gpu_target_subset(oracle_lib):
+    mesh = M.hex_mesh(8, jitter=0.1, seed=9)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0))
+    o = oracle_lib.OracleInterpolator("port", threads=2)
+    o.load_mesh(mesh)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    targets = np.array([400, 3, 77, 500, 81], dtype=np.int64)
+    for meth in ("idw", "ls", "gls"):
+        wo, no = o.prepare(meth, "u")
+        w, nw = I.prepare_interpolator(meth, "u", targets)
+        assert util.rowscaled_err(w, wo[targets]) <= util.WEIGHT_RTOL
+        assert util.rowscaled_err(nw, no[targets]) <= util.WEIGHT_RTOL
+        W, nws = I.interpolate("u", meth, targets)
+        assert W.shape == (len(targets), I.grid.n_elems)
