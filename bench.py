@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- the north-star line: GLS interpolate() on a synthetic 10 M-cell hexahedron mesh.
+
+    python bench.py --gpus 1 --steps K --warmup W                      (one GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the rank's shard: the GLS weight kernel over every node
+(inputs resident in HBM, output written in CSR position on the device) and, for N > 1, the one
+all-gather over RCCL that reassembles the (count, column, value) triplets on every rank.
+
+Workload (BASELINE.json: "GLS, 10M-cell hex mesh"): 216^3 = 10,077,696 hexahedra per GPU,
+nodes jittered U(-0.15h, 0.15h), K = the ALH tensor at the centroids, all-Dirichlet boundary flags.
+With N GPUs the box grows to 216 x 216 x 216 N cells (weak scaling): rank r owns a contiguous block of
+node planes, replicates one cell layer on each interior side, and no rank ever holds the whole mesh.
+
+Prints ONE JSON line on rank 0.  Besides the contract fields it carries
+  roofline      HBM roofline of the dominant kernel: algorithmic bytes (SURVEY 8d formula) / the kernel's
+                average duration measured with HIP events on the launch stream; `traffic` from
+                profiles/traffic.json when a PMC run has been recorded, else null
+  cpu_baseline  the reference's own GLS (oracle/_ref, kind "reference") -- or our C restatement
+                ("port") when _ref is absent -- timed on this box's host cores on a bounded sample
+  fp64          GLS is FP64-ALU-bound, not HBM-bound, in the reference formulation (SURVEY finding 2):
+                achieved reference-equivalent FLOP/s next to the 78.6 TFLOP/s vector peak.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6     # vector FP64
+REF_FLOPS_PER_NODE_HEX = 74.8e3   # dgels 44 x 25 x 8 per interior hexahedron node
+
+
+def cpu_baseline(method, n_sample, jitter):
+    """Time the CPU path on a bounded sample: the same mesh recipe at n_sample^3 cells."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    import ninpol_oracle as O
+    from ninpol_amd import mesh as M
+    kind = "reference" if O.have_reference() else "port"
+    try:
+        o = O.OracleInterpolator(kind)
+    except Exception:
+        kind = "port"
+        o = O.OracleInterpolator(kind)
+    cores = min(16, os.cpu_count() or 1)   # gls.pyx:87 hard-codes 16 OpenMP threads
+    o.threads = cores
+    m = M.hex_mesh(n_sample, jitter=jitter, seed=0)
+    M.attach_fields(m, "u", perm="ALH")
+    o.load_mesh(m)
+    t0 = time.time()
+    o.prepare(method, "u")
+    dt = time.time() - t0
+    P = o.grid.n_points
+    return {"value": round(P / dt / 1e6, 4), "unit": "Mnodes/s", "cores": cores, "kind": kind,
+            "sample": f"{method.upper()} prepare() on a {n_sample}^3-cell hex mesh of the same recipe "
+                      f"({P} nodes, {dt:.2f} s, method kernel only)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--method", default="gls", choices=["gls", "idw", "ls"])
+    ap.add_argument("--n", type=int, default=216, help="cells per edge per GPU (216^3 = 10,077,696)")
+    ap.add_argument("--jitter", type=float, default=0.15)
+    ap.add_argument("--cpu-sample", type=int, default=64, help="edge of the CPU-baseline sample mesh (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the IDW/LS context numbers and the e2e timing")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the weight kernels are HIP only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ninpol_amd
+    from ninpol_amd import mesh as M
+    from ninpol_amd.partition import node_block
+
+    n = args.n
+    nz_global = n * world
+    plane_lo, plane_hi = node_block(nz_global + 1, rank, world)
+    t0 = time.time()
+    mesh, node_off, cell_off, own_lo, own_hi = M.hex_slab(n, n, nz_global, plane_lo, plane_hi,
+                                                          lengths=(1.0, 1.0, float(world)), jitter=args.jitter, seed=0)
+    M.attach_fields(mesh, "u", perm="ALH")
+    t_gen = time.time() - t0
+    t0 = time.time()
+    I = ninpol_amd.Interpolator(device=local_rank)
+    I.load_mesh(mesh_obj=mesh)
+    t_load = time.time() - t0
+    del mesh
+    g = I.grid
+    t0 = time.time()
+    plan = I.device_plan("u", args.method)
+    t_push = time.time() - t0
+    P_loc, n_owned = g.n_points, own_hi - own_lo
+    esup_ptr = g.esup_ptr
+    eb, ee = int(esup_ptr[own_lo]), int(esup_ptr[own_hi])
+
+    stream = torch.cuda.current_stream()
+    counts_own = torch.from_numpy(np.diff(esup_ptr[own_lo:own_hi + 1]).astype(np.int32)).to(dev)
+    if world > 1:
+        # static parts of the triplets, global ids; padded so that every rank sends the same length
+        lens = torch.tensor([ee - eb, n_owned], dtype=torch.int64, device=dev)
+        all_lens = [torch.empty_like(lens) for _ in range(world)]
+        dist.all_gather(all_lens, lens)
+        all_lens = torch.stack(all_lens).cpu().numpy()
+        mx_nnz, mx_rows = int(all_lens[:, 0].max()), int(all_lens[:, 1].max())
+        cols_pad = torch.zeros(mx_nnz, dtype=torch.int32, device=dev)
+        cols_pad[:ee - eb] = torch.from_numpy((g.esup[eb:ee] + cell_off).astype(np.int32)).to(dev)
+        cnt_pad = torch.zeros(mx_rows, dtype=torch.int32, device=dev)
+        cnt_pad[:n_owned] = counts_own
+        g_vals = torch.empty(world * mx_nnz, dtype=torch.float64, device=dev)
+        g_cols = torch.empty(world * mx_nnz, dtype=torch.int32, device=dev)
+        g_cnt = torch.empty(world * mx_rows, dtype=torch.int32, device=dev)
+    else:
+        mx_nnz = ee - eb
+    out = torch.empty(max(plan.nnz, eb + mx_nnz), dtype=torch.float64, device=dev)
+    nws = torch.empty(P_loc, dtype=torch.float64, device=dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record(stream)
+        plan.launch(out.data_ptr(), nws.data_ptr(), stream.cuda_stream, add_neumann=True)
+        if i is not None:
+            ev[i][1].record(stream)
+        if world > 1:   # the single exchange step of the path: (count, column, value) of every owned row
+            dist.all_gather_into_tensor(g_vals, out[eb:eb + mx_nnz])
+            dist.all_gather_into_tensor(g_cols, cols_pad)
+            dist.all_gather_into_tensor(g_cnt, cnt_pad)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    if world > 1:
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+        tot = torch.tensor([n_owned], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        total_nodes = int(tot[0])
+    else:
+        total_nodes = n_owned
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_nodes * args.steps / elapsed / 1e6
+        B_alg = plan.algorithmic_bytes
+        ach = B_alg / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.method}_n{n}_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mnodes/s interpolated (GLS, 10M-cell hex mesh) + achieved HBM GB/s vs peak"
+                      if args.method == "gls" and n == 216 else f"Mnodes/s interpolated ({args.method.upper()}, {n}^3-cell hex mesh per GPU)",
+            "value": round(value, 3), "unit": "Mnodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.method.upper()} interpolate() weights, {n}x{n}x{n * world} hexahedra "
+                                   f"({n ** 3 * world} cells, {total_nodes} nodes), jitter {args.jitter}, ALH permeability, "
+                                   "all-Dirichlet boundary; inputs resident in HBM, output CSR values on device"
+                                   + ("; + RCCL all-gather of (count, column, value) per step" if world > 1 else ""),
+                       "cells_per_gpu": n ** 3, "nodes_total": total_nodes, "nnz_esup_rank0": plan.nnz,
+                       "parallelism": f"node-block shards x{world}, neighbour cells replicated" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": plan.kernel_name, "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": B_alg, "bytes_per_node": round(B_alg / P_loc, 1)},
+            "setup_s": {"mesh_gen": round(t_gen, 2), "load_mesh": round(t_load, 2), "push_to_hbm": round(t_push, 2)},
+        }
+        if args.method == "gls":
+            flops = REF_FLOPS_PER_NODE_HEX * P_loc / (kern_ms * 1e-3) / 1e12
+            line["fp64"] = {"ref_equiv_tflops": round(flops, 3), "peak_tflops": FP64_PEAK_TFLOPS,
+                            "frac": round(flops / FP64_PEAK_TFLOPS, 4),
+                            "note": "74.8 kflop/node = dgels 44x25x8 of the reference; GLS is FP64-bound (SURVEY finding 2)"}
+        if world == 1 and not args.no_extras:
+            # context: the two HBM-bound methods on the same grid, and end-to-end interpolate()
+            for meth in ("idw", "ls"):
+                if meth == args.method:
+                    continue
+                p2 = I.device_plan("u", meth)
+                for _ in range(2):
+                    p2.launch(out.data_ptr(), nws.data_ptr(), stream.cuda_stream)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                for _ in range(5):
+                    p2.launch(out.data_ptr(), nws.data_ptr(), stream.cuda_stream)
+                b.record(stream)
+                torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 5
+                line[meth] = {"kernel_ms": round(ms, 4), "Mnodes_per_s": round(P_loc / ms / 1e3, 1),
+                              "achieved_GBps": round(p2.algorithmic_bytes / (ms * 1e-3) / 1e9, 1),
+                              "frac_hbm": round(p2.algorithmic_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del out, nws
+            torch.cuda.empty_cache()
+            t0 = time.time()
+            W, _ = I.interpolate("u", args.method)
+            line["e2e_interpolate_s"] = round(time.time() - t0, 3)
+            line["e2e_nnz"] = int(W.nnz)
+        if world == 1 and args.cpu_sample > 0:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.method, args.cpu_sample, args.jitter)
+            except Exception as e:   # never lose the GPU line to the baseline leg
+                line["cpu_baseline"] = {"value": None, "unit": "Mnodes/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

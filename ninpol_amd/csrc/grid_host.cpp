@@ -55,7 +55,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     inpoel.resize((size_t)E * kMaxPointsPerElement);
     etype.resize((size_t)E);
     bool bad = false;
-#pragma omp parallel for schedule(static) reduction(|| : bad)
+#pragma omp parallel for schedule(dynamic, 16384) reduction(|| : bad)
     for (int64_t e = 0; e < E; ++e) {
         int64_t t = element_types[e];
         if (t < 0 || t >= kNumElementTypes) { bad = true; t = 0; }
@@ -69,7 +69,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     if (bad) return -1;
 
     coords.assign((size_t)P * 3, 0.0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t p = 0; p < P; ++p)
         for (int k = 0; k < coords_dim && k < 3; ++k) coords[p * 3 + k] = xyz[p * coords_dim + k];
 
@@ -78,9 +78,9 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     esup_ptr.assign((size_t)P + 1, 0);
     {
         std::vector<std::atomic<int32_t>> cnt((size_t)P);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
         for (int64_t p = 0; p < P; ++p) cnt[p].store(0, std::memory_order_relaxed);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
         for (int64_t e = 0; e < E; ++e) {
             int n = npoel[etype[e]];
             for (int j = 0; j < n; ++j) cnt[inpoel[e * 8 + j]].fetch_add(1, std::memory_order_relaxed);
@@ -96,9 +96,9 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
         mx_elems_per_point = mx;
         if (run >= INT32_MAX) return -5;
         esup.resize((size_t)run);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
         for (int64_t p = 0; p < P; ++p) cnt[p].store(0, std::memory_order_relaxed);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
         for (int64_t e = 0; e < E; ++e) {
             int n = npoel[etype[e]];
             for (int j = 0; j < n; ++j) {
@@ -107,14 +107,14 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
                 esup[esup_ptr[p] + at] = (int32_t)e;
             }
         }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
         for (int64_t p = 0; p < P; ++p) std::sort(esup.begin() + esup_ptr[p], esup.begin() + esup_ptr[p + 1]);
     }
 
     lap("esup");
     // ---- esuel (grid.pyx:449-525) -----------------------------------------------------------
     esuel.assign((size_t)E * kMaxFacesPerElement, -1);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t ie = 0; ie < E; ++ie) {
         const int it = etype[ie];
         const int32_t *el = &inpoel[ie * 8];
@@ -157,7 +157,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     // ---- infael / inpofa: global face numbering (grid.pyx:304-345) --------------------------
     infael.assign((size_t)E * kMaxFacesPerElement, -1);
     std::vector<int64_t> own_start((size_t)E + 1, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t e = 0; e < E; ++e) {
         int c = 0;
         for (int j = 0; j < nfael[etype[e]]; ++j) {
@@ -171,7 +171,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     if (n_faces * 4 >= INT32_MAX) return -5;
     std::vector<int32_t> face_owner((size_t)n_faces);   // creating element
     std::vector<int8_t> face_owner_lf((size_t)n_faces);  // its local face
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t e = 0; e < E; ++e) {
         int64_t f = own_start[e];
         for (int j = 0; j < nfael[etype[e]]; ++j) {
@@ -184,7 +184,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
             }
         }
     }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t e = 0; e < E; ++e) {
         for (int j = 0; j < nfael[etype[e]]; ++j) {
             int32_t k = esuel[e * 6 + j];
@@ -196,7 +196,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     }
     const int64_t F = n_faces;
     inpofa.assign((size_t)F * kMaxPointsPerFace, -1);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t f = 0; f < F; ++f) {
         const int64_t e = face_owner[f];
         const int t = etype[e], j = face_owner_lf[f];
@@ -225,7 +225,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
 #pragma omp parallel reduction(max : mxf)
     {
         std::vector<int32_t> buf(fbuf);
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 16384)
         for (int64_t p = 0; p < P; ++p) {
             int n = gather_faces(p, buf.data());
             fsup_ptr[p + 1] = n;
@@ -239,7 +239,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
 #pragma omp parallel
     {
         std::vector<int32_t> buf(fbuf);
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 16384)
         for (int64_t p = 0; p < P; ++p) {
             int n = gather_faces(p, buf.data());
             std::copy(buf.begin(), buf.begin() + n, fsup.begin() + fsup_ptr[p]);
@@ -252,7 +252,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     boundary_faces.assign((size_t)F, 0);
     boundary_points.assign((size_t)P, 0);
     int64_t mxe = 0;
-#pragma omp parallel for schedule(static) reduction(max : mxe)
+#pragma omp parallel for schedule(dynamic, 16384) reduction(max : mxe)
     for (int64_t f = 0; f < F; ++f) {
         const int32_t nb = esuel[(int64_t)face_owner[f] * 6 + face_owner_lf[f]];
         esuf_ptr[f + 1] = nb == -1 ? 1 : 2;
@@ -261,7 +261,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     mx_elems_per_face = mxe;
     for (int64_t f = 0; f < F; ++f) esuf_ptr[f + 1] += esuf_ptr[f];
     esuf.resize((size_t)esuf_ptr[F]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t f = 0; f < F; ++f) {
         const int32_t nb = esuel[(int64_t)face_owner[f] * 6 + face_owner_lf[f]];
         esuf[esuf_ptr[f]] = face_owner[f];
@@ -276,7 +276,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     // ---- geometry (grid.pyx:669-809) -----------------------------------------------------------
     centroids.assign((size_t)E * 3, 0.0);
     const int d = (int)dim;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t e = 0; e < E; ++e) {
         const int n = npoel[etype[e]];
         for (int j = 0; j < n; ++j)
@@ -286,7 +286,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     normal_faces.assign((size_t)F * 3, 0.0f);
     faces_areas.assign((size_t)F, 0.0);
     const double *X = coords.data();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t f = 0; f < F; ++f) {
         int npofa = 0;
         for (int j = 0; j < kMaxPointsPerFace && inpofa[f * 4 + j] != -1; ++j) {
@@ -352,7 +352,7 @@ void HostGrid::build_psup() {
 #pragma omp parallel reduction(max : mx)
     {
         std::vector<int32_t> buf;
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 16384)
         for (int64_t p = 0; p < P; ++p) {
             gather(p, buf);
             psup_ptr[p + 1] = (int64_t)buf.size();
@@ -365,7 +365,7 @@ void HostGrid::build_psup() {
 #pragma omp parallel
     {
         std::vector<int32_t> buf;
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 16384)
         for (int64_t p = 0; p < P; ++p) {
             gather(p, buf);
             std::copy(buf.begin(), buf.end(), psup.begin() + psup_ptr[p]);

@@ -297,6 +297,10 @@ class Interpolator:
         W.eliminate_zeros()
         return W, nws
 
+    def device_plan(self, variable, method):
+        """Upload the fields of (variable, method) and return a DevicePlan (kernel-only launches)."""
+        return DevicePlan(self, variable, method)
+
     def prepare_interpolator(self, method, variable, target_points):
         """interpolator.pyx:631-670: dense (n_target, MX_ELEMENTS_PER_POINT) weights + neumann_ws."""
         target_points = np.asarray(target_points, dtype=DTYPE_I)
@@ -305,3 +309,42 @@ class Interpolator:
         self.supported_methods[method](self.grid, self.cells_data, self.points_data, self.faces_data,
                                        self.variable_to_index, variable, target_points, weights, neumann_ws)
         return weights, neumann_ws
+
+
+class DevicePlan:
+    """Device-resident form of one `interpolate(variable, method)`: the field rows are uploaded once
+    and every `launch` is just the kernel, asynchronous on the caller's HIP stream, writing into the
+    caller's device buffers (e.g. torch tensors): csr_data [nnz_esup] float64, neumann_ws [n_points]
+    float64.  This is what bench.py times and what the multi-GPU path feeds to the all-gather."""
+
+    def __init__(self, interp, variable, method):
+        if not interp.is_grid_initialized:
+            raise ValueError("Grid not initialized. Please load a mesh first.")
+        if method not in interp.supported_methods:
+            raise ValueError(f"Method '{method}' not supported. Supported methods are: "
+                             f"{list(interp.supported_methods.keys())}")
+        self.grid = g = interp.grid
+        self.method = method
+        self.method_id = _lib.METHOD_ID[method]
+        L = _lib.load()
+        if g.device < 0:
+            g.to_device(interp.device)
+        P, E = g.n_points, g.n_elems
+        v2i = interp.variable_to_index
+        flag = np.ascontiguousarray(np.asarray(interp.points_data)[v2i["points"]["neumann_flag_" + variable]][:P],
+                                    dtype=DTYPE_F)
+        perm = dmag = None
+        if "permeability" in v2i["cells"]:
+            cd = np.asarray(interp.cells_data)
+            perm = np.ascontiguousarray(cd[v2i["cells"]["permeability"]][:E * 9], dtype=DTYPE_F)
+            dmag = np.ascontiguousarray(cd[v2i["cells"]["diff_mag"]][:E], dtype=DTYPE_F)
+        _lib.check(L.nin_fields_set(g._h, _ptr(perm), _ptr(dmag), _ptr(flag), None))
+        self.nnz = int(L.nin_grid_scalar(g._h, b"nnz_esup"))
+        self.n_points = P
+        self.algorithmic_bytes = int(L.nin_algorithmic_bytes(g._h, self.method_id))
+        self.kernel_name = L.nin_kernel_name(self.method_id).decode()
+
+    def launch(self, csr_data_ptr, neumann_ws_ptr, stream=0, add_neumann=True):
+        _lib.check(_lib.load().nin_weights_device(self.grid._h, self.method_id, None, 0, int(bool(add_neumann)),
+                                                  ctypes.c_void_p(csr_data_ptr), ctypes.c_void_p(neumann_ws_ptr),
+                                                  ctypes.c_void_p(stream)))

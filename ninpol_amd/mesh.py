@@ -48,25 +48,30 @@ class Mesh:
 # structured generators
 # ------------------------------------------------------------------------------------------------
 
-def _lattice_points(nx, ny, nz, lengths, origin, jitter, seed):
+def _lattice_points(nx, ny, nz, lengths, origin, jitter, seed, k0=0, k1=None):
+    """Lattice nodes of planes k0..k1 (inclusive) of the global (nx, ny, nz) box, x fastest.
+
+    Jitter is drawn per z-plane from default_rng([seed, k]) so that any z-slab of the mesh can be
+    generated on its own (one slab per GPU rank) and agrees with the whole mesh on shared planes."""
+    k1 = nz if k1 is None else k1
     x = np.linspace(0.0, lengths[0], nx + 1) + origin[0]
     y = np.linspace(0.0, lengths[1], ny + 1) + origin[1]
-    z = np.linspace(0.0, lengths[2], nz + 1) + origin[2]
+    z = np.linspace(0.0, lengths[2], nz + 1)[k0:k1 + 1] + origin[2]
     Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
     pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
     if jitter:
-        rng = np.random.default_rng(seed)
         h = np.array([lengths[0] / nx, lengths[1] / ny, lengths[2] / nz])
-        d = rng.uniform(-jitter, jitter, size=pts.shape) * h
-        # keep the box: boundary nodes only move inside their boundary plane
-        I = np.arange(pts.shape[0])
-        i = I % (nx + 1)
-        j = (I // (nx + 1)) % (ny + 1)
-        k = I // ((nx + 1) * (ny + 1))
-        d[(i == 0) | (i == nx), 0] = 0.0
-        d[(j == 0) | (j == ny), 1] = 0.0
-        d[(k == 0) | (k == nz), 2] = 0.0
-        pts = pts + d
+        npl = (nx + 1) * (ny + 1)
+        I = np.arange(npl)
+        i, j = I % (nx + 1), I // (nx + 1)
+        for k in range(k0, k1 + 1):
+            d = np.random.default_rng([seed, k]).uniform(-jitter, jitter, size=(npl, 3)) * h
+            # keep the box: boundary nodes only move inside their boundary plane
+            d[(i == 0) | (i == nx), 0] = 0.0
+            d[(j == 0) | (j == ny), 1] = 0.0
+            if k == 0 or k == nz:
+                d[:, 2] = 0.0
+            pts[(k - k0) * npl:(k - k0 + 1) * npl] += d
     return np.ascontiguousarray(pts)
 
 
@@ -89,6 +94,21 @@ def hex_mesh(nx, ny=None, nz=None, lengths=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.
     nz = nx if nz is None else nz
     pts = _lattice_points(nx, ny, nz, lengths, origin, jitter, seed)
     return Mesh(pts, [CellBlock("hexahedron", _hex_corner_ids(nx, ny, nz))])
+
+
+def hex_slab(nx, ny, nz, plane_lo, plane_hi, lengths=(1.0, 1.0, 1.0), jitter=0.0, seed=0):
+    """The part of hex_mesh(nx, ny, nz) a rank owning node planes [plane_lo, plane_hi) needs: those
+    planes plus one halo plane on each interior side, and every cell between them.  Returns
+    (mesh, node_offset, cell_offset, owned_lo, owned_hi): local ids + offset = global ids, and the
+    owned nodes are the local range [owned_lo, owned_hi).  Nodes partition by contiguous index
+    blocks with the neighbouring cells replicated (north_star)."""
+    k0 = max(plane_lo - 1, 0)
+    k1 = min(plane_hi, nz)            # last node plane kept (inclusive)
+    pts = _lattice_points(nx, ny, nz, lengths, (0.0, 0.0, 0.0), jitter, seed, k0, k1)
+    cells = _hex_corner_ids(nx, ny, k1 - k0)
+    npl = (nx + 1) * (ny + 1)
+    mesh = Mesh(pts, [CellBlock("hexahedron", cells)])
+    return mesh, k0 * npl, k0 * nx * ny, (plane_lo - k0) * npl, (plane_hi - k0) * npl
 
 
 # the six Kuhn simplices of the unit cube as paths 0 -> 6 through hexahedron-local corners,

@@ -1,0 +1,132 @@
+"""Multi-GPU path: node-block sharding + one all-gather of the result (no other collective).
+
+Every node's weight row depends only on its own esup / fsup rows and the cells / faces they reference
+(the prange bodies idw.pyx:57-84, ls.pyx:56-135, gls.pyx:161-219 touch only row `point`), so the path
+shards with no exchange during compute:
+
+  * rank r owns the contiguous node block [P r / W, P (r+1) / W);
+  * it keeps every cell that touches an owned node (the neighbouring cells are replicated), in the
+    original relative order, and renumbers points / cells locally.  All cells and faces around an
+    owned node are present, local ids are monotone in global ids, so each owned node sees exactly the
+    rows it sees in the whole mesh, in the same order: results are bit-identical to a single-GPU run;
+  * after the kernels, ONE all-gather with per-rank counts (allgatherv) reassembles the rows:
+    per owned node its entry count, per entry (global column int32, value float64).  Over RCCL the
+    uneven sizes are handled by exchanging the counts first and padding to the largest shard.
+
+torch.distributed is plumbing only (process group + the collective); backend "nccl" is RCCL over xGMI
+on the GPU box and "gloo" in the CPU tests.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from . import topology as T
+from .mesh import CellBlock, Mesh
+
+
+def node_block(n_points, rank, world):
+    """[lo, hi) of the contiguous node-index block of `rank`."""
+    return (n_points * rank) // world, (n_points * (rank + 1)) // world
+
+
+def extract_submesh(mesh, lo, hi):
+    """Cells touching a node in [lo, hi) + the points they use, relative order preserved.
+
+    Returns (submesh, point_ids, cell_ids, owned): point_ids / cell_ids map local -> global ids
+    (ascending), `owned` are the LOCAL ids of the nodes in [lo, hi) (ascending)."""
+    dim = T.mesh_dimension([b.type for b in mesh.cells])
+    keep_blocks, cell_ids, used = [], [], []
+    goff = 0
+    for b in mesh.cells:
+        if b.type not in T.TYPES_PER_DIMENSION[dim]:
+            keep_blocks.append(None)
+            continue
+        d = np.asarray(b.data)
+        m = ((d >= lo) & (d < hi)).any(axis=1)
+        keep_blocks.append(m)
+        cell_ids.append(goff + np.nonzero(m)[0])
+        used.append(np.unique(d[m]))
+        goff += len(d)
+    point_ids = np.unique(np.concatenate(used)) if used else np.zeros(0, dtype=np.int64)
+    cells, cell_data = [], {k: [] for k in mesh.cell_data}
+    for bi, (b, m) in enumerate(zip(mesh.cells, keep_blocks)):
+        if m is None or not m.any():
+            continue
+        cells.append(CellBlock(b.type, np.searchsorted(point_ids, np.asarray(b.data)[m])))
+        for k in mesh.cell_data:
+            cell_data[k].append(np.asarray(mesh.cell_data[k][bi])[m])
+    point_data = {k: np.asarray(v)[point_ids] for k, v in mesh.point_data.items()}
+    sub = Mesh(np.asarray(mesh.points)[point_ids], cells, point_data, cell_data)
+    owned = np.nonzero((point_ids >= lo) & (point_ids < hi))[0]
+    return sub, point_ids, np.concatenate(cell_ids) if cell_ids else np.zeros(0, dtype=np.int64), owned
+
+
+def allgatherv(tensors, counts_hint=None, group=None):
+    """All-gather 1-D tensors whose length differs per rank.  `tensors` is a list of same-length-role
+    tensors of this rank (e.g. [values f64, columns i32]) sharing one length; returns, per input, the
+    list of every rank's piece.  One count exchange + one padded all_gather per tensor."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = tensors[0].device
+    n = torch.tensor([t.numel() for t in tensors], dtype=torch.int64, device=dev)
+    all_n = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(all_n, n, group=group)
+    all_n = torch.stack(all_n).cpu().numpy()          # (world, len(tensors))
+    out = []
+    for i, t in enumerate(tensors):
+        mx = int(all_n[:, i].max())
+        pad = torch.zeros(mx, dtype=t.dtype, device=dev)
+        pad[:t.numel()] = t
+        buf = torch.empty(world * mx, dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(buf, pad, group=group)
+        out.append([buf[r * mx:r * mx + int(all_n[r, i])] for r in range(world)])
+    return out
+
+
+class ShardedInterpolator:
+    """`interpolate()` over a process group: every rank loads the same mesh object, computes the rows
+    of its node block on its own GPU and receives the whole (n_points x n_elems) matrix.
+
+    make_interpolator: factory for the per-rank compute object (default: ninpol_amd.Interpolator on
+    this rank's GPU).  The CPU tests inject the oracle here; the product path never does."""
+
+    def __init__(self, group=None, device=None, make_interpolator=None):
+        import torch.distributed as dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = device
+        self._make = make_interpolator
+        self.local = None
+
+    def load_mesh(self, mesh_obj):
+        self.n_points = int(np.asarray(mesh_obj.points).shape[0])
+        self.lo, self.hi = node_block(self.n_points, self.rank, self.world)
+        sub, self.point_ids, self.cell_ids, self.owned = extract_submesh(mesh_obj, self.lo, self.hi)
+        dim = T.mesh_dimension([b.type for b in mesh_obj.cells])
+        self.n_elems = int(sum(len(b.data) for b in mesh_obj.cells if b.type in T.TYPES_PER_DIMENSION[dim]))
+        if self._make is None:
+            from .interpolator import Interpolator
+            self.local = Interpolator(device=self.device if self.device is not None else 0)
+        else:
+            self.local = self._make()
+        self.local.load_mesh(mesh_obj=sub)
+
+    def interpolate(self, variable, method):
+        import torch
+        W, nws = self.local.interpolate(variable, method)          # local (P_loc x E_loc), zeros eliminated
+        W = W.tocsr()[self.owned]                                  # rows of the owned block, ascending
+        cols = self.cell_ids[W.indices].astype(np.int32)           # local -> global cell id
+        dev = torch.device("cpu") if self.device is None else torch.device("cuda", self.device)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        row_nnz = np.diff(W.indptr).astype(np.int32)
+        pieces = allgatherv([t(W.data), t(cols)], group=self.group)
+        rows = allgatherv([t(row_nnz), t(np.ascontiguousarray(nws[self.owned]))], group=self.group)
+        data = torch.cat(pieces[0]).cpu().numpy()
+        indices = torch.cat(pieces[1]).cpu().numpy()
+        counts = torch.cat(rows[0]).cpu().numpy().astype(np.int64)
+        neumann = torch.cat(rows[1]).cpu().numpy()
+        indptr = np.concatenate([[0], np.cumsum(counts)])
+        idx_t = np.int32 if max(len(data), self.n_elems, self.n_points) < np.iinfo(np.int32).max else np.int64
+        full = sp.csr_matrix((data, indices.astype(idx_t), indptr.astype(idx_t)), shape=(self.n_points, self.n_elems))
+        return full, neumann

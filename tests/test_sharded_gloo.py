@@ -1,0 +1,105 @@
+"""N > 1 path on CPU: world_size-2 gloo.  The partition (node blocks + replicated neighbour cells),
+the local->global index maps and the allgatherv are the product's (ninpol_amd/partition.py); the
+per-rank compute is the oracle here because the HIP kernels need a GPU -- this is a test, the
+product path never routes through the oracle.  Expectation: the gathered matrix is bit-identical
+to the single-process result (same rows, same order, same arithmetic)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import util  # noqa: F401  (path setup via conftest)
+from ninpol_amd import mesh as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_mesh(kind):
+    if kind == "mixed":
+        m = M.mixed_mesh(8, 4, 4, jitter=0.1, seed=3)
+    else:
+        m = M.hex_mesh(6, 5, 7, jitter=0.15, seed=1)
+    M.attach_fields(m, "u", perm="ALH", neumann_plane=(2, 0.0), seed=5)
+    return m
+
+
+class _OracleCompute:
+    def __init__(self):
+        import ninpol_oracle
+        self.o = ninpol_oracle.OracleInterpolator("port", threads=1)
+
+    def load_mesh(self, filename="", mesh_obj=None):
+        self.o.load_mesh(mesh_obj)
+
+    def interpolate(self, variable, method):
+        return self.o.interpolate(variable, method)
+
+
+def _worker(rank, world, port, kind, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from ninpol_amd.partition import ShardedInterpolator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mesh = _make_mesh(kind)
+        S = ShardedInterpolator(device=None, make_interpolator=_OracleCompute)
+        S.load_mesh(mesh)
+        for meth in ("idw", "ls", "gls"):
+            W, nws = S.interpolate("u", meth)
+            np.savez(os.path.join(out_dir, f"r{rank}_{meth}.npz"), indptr=W.indptr, indices=W.indices,
+                     data=W.data, nws=nws)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["hex", "mixed"])
+def test_two_rank_gather_matches_single(tmp_path, oracle_lib, kind):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
+    mesh = _make_mesh(kind)
+    o = oracle_lib.OracleInterpolator("port", threads=1)
+    o.load_mesh(mesh)
+    for meth in ("idw", "ls", "gls"):
+        W, nws = o.interpolate("u", meth)
+        for r in range(world):
+            z = np.load(os.path.join(str(tmp_path), f"r{r}_{meth}.npz"))
+            np.testing.assert_array_equal(z["indptr"], W.indptr)
+            np.testing.assert_array_equal(z["indices"], W.indices)
+            np.testing.assert_array_equal(z["data"], W.data)
+            np.testing.assert_array_equal(z["nws"], nws)
+
+
+def test_extract_submesh_invariants():
+    from ninpol_amd.partition import extract_submesh, node_block
+    mesh = _make_mesh("mixed")
+    P = mesh.points.shape[0]
+    seen = np.zeros(P, dtype=int)
+    for r in range(3):
+        lo, hi = node_block(P, r, 3)
+        sub, pid, cid, owned = extract_submesh(mesh, lo, hi)
+        assert np.all(np.diff(pid) > 0) and np.all(np.diff(cid) > 0)
+        assert np.array_equal(pid[owned], np.arange(lo, hi))
+        seen[lo:hi] += 1
+        # every global cell touching an owned node is present
+        goff = 0
+        for b in mesh.cells:
+            touch = ((b.data >= lo) & (b.data < hi)).any(axis=1)
+            assert np.isin(goff + np.nonzero(touch)[0], cid).all()
+            goff += len(b.data)
+        np.testing.assert_array_equal(sub.points, mesh.points[pid])
+    assert np.all(seen == 1)
