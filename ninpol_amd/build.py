@@ -22,6 +22,7 @@ UNITS = [
     # IDW / LS: contraction off so results are the reference's bit for bit
     ("kernels_idw_ls.hip", "hipcc", ["-ffp-contract=off"]),
     ("kernels_gls.hip", "hipcc", []),
+    ("kernels_gls_group.hip", "hipcc", []),
     ("kernels_csr.hip", "hipcc", []),
     ("abi.hip", "hipcc", ["-Wno-unknown-pragmas"]),
 ]

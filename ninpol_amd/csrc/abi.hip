@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -284,11 +285,18 @@ int nin_grid_to_device(nin_grid *g, int device) {
     // ---- GLS launch plan: bin nodes by the size of their least-squares system -----------------------
     g->node_class.assign((size_t)P, 0);
     std::vector<std::vector<int32_t>> lists(kGlsClasses);
+    std::vector<int32_t> hex8_list;
+    const bool use_group = getenv("NIN_GLS_NO_GROUP") == nullptr;   // debugging switch: force the generic kernel
     int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0};
     for (int64_t p = 0; p < P; ++p) {
         const int64_t ne = h.esup_ptr[p + 1] - h.esup_ptr[p], nf = h.fsup_ptr[p + 1] - h.fsup_ptr[p];
         int64_t nbf = 0;
         for (int64_t q = h.fsup_ptr[p]; q < h.fsup_ptr[p + 1]; ++q) nbf += h.boundary_faces[h.fsup[q]];
+        if (use_group && ne == 8 && nf == 12 && nbf == 0 && h.dim == 3) {
+            g->node_class[p] = 255;
+            hex8_list.push_back((int32_t)p);
+            continue;
+        }
         const int64_t m = ne + 3 * (nf - nbf) + nbf, n = 3 * ne + 1;
         const int64_t doubles = ((ne + 1) >> 1) + n + m * n;
         const int64_t bytes = ((doubles * 8 + 15) / 16) * 16;
@@ -309,6 +317,13 @@ int nin_grid_to_device(nin_grid *g, int device) {
         const int32_t *lp = nullptr;
         if (k.count && (rc = dev_upload(d, &lp, lists[c]))) return rc;
         k.nodes = const_cast<int32_t *>(lp);
+    }
+    {
+        d.hex8.count = (int32_t)hex8_list.size();
+        const int32_t *lp = nullptr;
+        if (d.hex8.count && (rc = dev_upload(d, &lp, hex8_list))) return rc;
+        d.hex8.nodes = const_cast<int32_t *>(lp);
+        if (d.hex8.count == P) d.hex8.nodes = nullptr;
     }
     if (d.gls[kGlsClasses - 1].count) {
         d.gls_scratch_slots = 1024;
@@ -367,6 +382,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, nullptr, (int32_t)P, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, dev_csr_data, dev_neumann_ws, stream);
         else {
+            rc = launch_gls_hex8(d.v, d.hex8.nodes, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             for (int c = 0; c < kGlsClasses && !rc; ++c) {
                 auto &k = d.gls[c];
                 rc = launch_gls_class(d.v, k.nodes, k.count, k.lds_bytes, k.rows_per_lane, add_neumann, dev_csr_data,
@@ -382,9 +398,10 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     HIP_TRY(hipMemsetAsync(dev_csr_data, 0, (size_t)d.nnz_e * 8, stream));
     HIP_TRY(hipMemsetAsync(dev_neumann_ws, 0, (size_t)P * 8, stream));
     if (n_targets == 0) return NIN_OK;
-    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses : 1);
+    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 1 : 1);
     for (int64_t i = 0; i < n_targets; ++i) {
-        const int c = method == NIN_METHOD_GLS ? g->node_class[targets[i]] : 0;
+        int c = method == NIN_METHOD_GLS ? g->node_class[targets[i]] : 0;
+        if (c == 255) c = kGlsClasses;   // the hex8 group-kernel class
         lists[c].push_back((int32_t)targets[i]);
     }
     for (size_t c = 0; c < lists.size() && !rc; ++c) {
@@ -396,6 +413,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         const int32_t cnt = (int32_t)lists[c].size();
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, dev_csr_data, dev_neumann_ws, stream);
+        else if ((int)c == kGlsClasses) rc = launch_gls_hex8(d.v, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else rc = launch_gls_class(d.v, dl, cnt, d.gls[c].lds_bytes, d.gls[c].rows_per_lane, add_neumann, dev_csr_data,
                                    dev_neumann_ws, d.gls_scratch, d.gls_scratch_stride, d.gls_scratch_slots, stream);
         HIP_TRY(hipFreeAsync(dl, stream));
@@ -481,7 +499,7 @@ int64_t nin_algorithmic_bytes(const nin_grid *g, int method) {
 const char *nin_kernel_name(int method) {
     if (method == NIN_METHOD_IDW) return "nin_idw_kernel";
     if (method == NIN_METHOD_LS) return "nin_ls_kernel";
-    return kernel_name_gls();
+    return kernel_name_gls_hex8();   // dominant on hexahedron meshes; kernel_name_gls() covers the other nodes
 }
 
 }  // extern "C"

@@ -43,6 +43,7 @@ struct DeviceGrid {
         int32_t rows_per_lane = 1; // ceil(max rows / 64)
         int32_t max_cells = 0, max_cols = 0, max_rows = 0;
     } gls[kGlsClasses];
+    GlsClass hex8;  // nodes with exactly 8 cells and 12 faces, all internal: kernels_gls_group.hip
     double *gls_scratch = nullptr;  // global-memory systems for the oversize class
     int64_t gls_scratch_stride = 0; // doubles per wave slot
     int32_t gls_scratch_slots = 0;

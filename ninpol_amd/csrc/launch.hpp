@@ -17,6 +17,10 @@ int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, doub
 int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes,
                      int32_t rows_per_lane, int add_neumann, double *out, double *nws,
                      double *scratch, int64_t scratch_stride, int32_t scratch_slots, hipStream_t stream);
+// the register-resident group kernel for (8 cells, 12 internal faces) nodes, kernels_gls_group.hip
+int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out,
+                    double *nws, hipStream_t stream);
+const char *kernel_name_gls_hex8();
 // out[j] += nws[row(j)] for IDW / LS is a no-op (their neumann_ws is 0): nothing to launch.
 
 // CSR finish (interpolator.pyx:622-624): count non-zeros per row, scan, compact
