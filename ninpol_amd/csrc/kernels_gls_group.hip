@@ -58,6 +58,37 @@ __device__ __forceinline__ double group16_sum(double v) {
     return v;
 }
 
+// LDS pointers are kept in their own address space and laundered once per node: a DS instruction takes
+// base VGPR + immediate offset, but only small immediates fit the paired forms (ds_read2_b64: 255 x 8 B),
+// and when the compiler sees the whole "node base + array offset + row" sum it hoists one base VGPR per
+// PAIR of rows out of the node loop (measured: ~100 VGPRs of addresses, spilled).  A laundered pointer is
+// an opaque base, so every access below is that base + a small compile-time offset.
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ lds_f64 *lds_base(double *p) {
+    lds_f64 *q = (lds_f64 *)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+
+// 1/d and 1/sqrt(s) from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) plus two Newton steps: full
+// double precision to a few ulp, a third of the instructions and of the dependent latency of the IEEE
+// division / sqrt expansions.  They only feed the reflector scalars, where an ulp-level error is an
+// ulp-level departure of H from orthogonality (parity bar: 1e-10).
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+    double e = fma(-s * y, y, 1.0);            // 1 - s y^2
+    y = fma(y * e, fma(e, 0.375, 0.5), y);     // y (1 + e/2 + 3 e^2/8)
+    e = fma(-s * y, y, 1.0);
+    y = fma(y * e, 0.5, y);
+    return y;
+}
+
 __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -71,45 +102,54 @@ struct Hex8 {
     static constexpr int SLOTS = NA / 8;     // 3 columns per lane
     static constexpr int HR = M / 2;         // 22 local rows per half
     static constexpr int CS = (M + 15) / 16; // 3 rows of c per lane
-    static constexpr int FR = 20;            // doubles per face record in LDS
-    static constexpr int NODE_DOUBLES = NIF * FR + M + NE / 2 + NA;
+    static constexpr int STAGE = 8 * M;      // staging buffer: the 8 columns of one register slot, column-major
+    static constexpr int NODE_DOUBLES = STAGE + M + NE / 2 + NA;
     static constexpr int LANES = 16, NODES_PER_WAVE = 4;
 };
 
 // One Householder step K (compile-time).  l8: column lane, h: row half, l16 = 8 h + l8.
 template <int K>
-__device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], double (&cr)[Hex8::CS], double *xb,
-                                        int l8, int h, int l16) {
+__device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], double (&cr)[Hex8::CS], double (&rinv)[Hex8::SLOTS],
+                                        double *xb, lds_f64 *xh, const lds_f64 *xc, int l8, int h, int l16) {
+    // xh = xb + h * HR (this lane's half of the published column), xc = xb + (l16 & 1) * HR + (l16 >> 1) (the
+    // rows l16 + 16 e of it): every LDS access below is pointer + compile-time offset, which the DS
+    // instructions take as an immediate -- indexing xb[h * HR + rl] instead costs one VGPR per address.
     using C = Hex8;
     constexpr int QK = K / 8, LK = K % 8, HP = K % 2, PL = K / 2, RL0 = (K + 1) / 2, HR = C::HR;
     const bool owner = (l8 == LK);
     const bool pivot_half = (h == HP);
     if (owner) {
 #pragma unroll
-        for (int rl = PL; rl < HR; ++rl) xb[h * HR + rl] = a[QK][rl];
+        for (int rl = PL; rl < HR; ++rl) xh[rl] = a[QK][rl];
     }
     lds_sync();
-    // this lane's half of the published column, rows strictly below the pivot
-    double x[HR];
-#pragma unroll
-    for (int rl = RL0; rl < HR; ++rl) x[rl] = xb[h * HR + rl];
-    if (HP == 0) x[PL] = (h == 0) ? 0.0 : x[PL];   // K even: local row PL of half 0 IS the pivot row
+    // pass 1 over this lane's half of the published column (rows strictly below the pivot): |x|^2 and the
+    // dot products with the lane's own columns.  x is NOT kept in registers between the passes: 22 more
+    // doubles would push the kernel past 256 VGPRs into scratch (measured: 25 GB of spill writes per launch).
     const double alpha = xb[HP * HR + PL];
     double ss = 0.0, d[C::SLOTS];
 #pragma unroll
     for (int q = 0; q < C::SLOTS; ++q) d[q] = 0.0;
 #pragma unroll
     for (int rl = RL0; rl < HR; ++rl) {
-        ss = fma(x[rl], x[rl], ss);
+        double xr = xh[rl];
+        if (HP == 0 && rl == PL) xr = (h == 0) ? 0.0 : xr;   // K even: local row PL of half 0 IS the pivot row
+        ss = fma(xr, xr, ss);
 #pragma unroll
-        for (int q = QK; q < C::SLOTS; ++q) d[q] = fma(x[rl], a[q][rl], d[q]);
+        for (int q = QK; q < C::SLOTS; ++q) d[q] = fma(xr, a[q][rl], d[q]);
     }
     ss += partner(ss);
-    // beta = -sign(alpha) |(alpha, x)| (dlarfg);  H = I - g v v^T,  v = (alpha - beta, x),  g = 1 / (beta (beta - alpha))
+    // beta = -sign(alpha) |(alpha, x)| (dlarfg);  H = I - g v v^T,  v = (alpha - beta, x),
+    // g = 1 / (beta (beta - alpha)) = 1 / (S + |alpha| sqrt(S)),  S = alpha^2 + |x|^2;  1 / beta = g (beta - alpha)
     const bool live = ss != 0.0;
-    const double beta = live ? -copysign(sqrt(fma(alpha, alpha, ss)), alpha) : alpha;
+    const double S = fma(alpha, alpha, ss);
+    const double rs = fast_rsqrt(S), sq = S * rs;                       // sqrt(S)
+    const double beta = live ? -copysign(sq, alpha) : alpha;
     const double vk = alpha - beta;
-    const double gk = live ? 1.0 / (beta * (beta - alpha)) : 0.0;
+    const double gden = fast_rcp(live ? fma(fabs(alpha), sq, S) : alpha);
+    const double gk = live ? gden : 0.0;
+    const double rinv_k = live ? -(gden * vk) : gden;                    // 1 / R(K,K), for the back-substitution
+    if (owner) rinv[QK] = rinv_k;
     if (owner && pivot_half) a[QK][PL] = beta;   // R(K,K); the rest of this column is dead from here on
     double gw[C::SLOTS];
 #pragma unroll
@@ -120,10 +160,13 @@ __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], doub
         gw[q] = act ? -(gk * w) : 0.0;
         if (pivot_half) a[q][PL] = fma(gw[q], vk, a[q][PL]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // pass 2 re-reads x from LDS
 #pragma unroll
     for (int rl = RL0; rl < HR; ++rl) {
+        double xr = xh[rl];
+        if (HP == 0 && rl == PL) xr = (h == 0) ? 0.0 : xr;
 #pragma unroll
-        for (int q = QK; q < C::SLOTS; ++q) a[q][rl] = fma(gw[q], x[rl], a[q][rl]);
+        for (int q = QK; q < C::SLOTS; ++q) a[q][rl] = fma(gw[q], xr, a[q][rl]);
     }
     // the last column c, dealt by rows: lane l16 holds rows l16, l16 + 16, l16 + 32
     {
@@ -132,7 +175,7 @@ __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], doub
         for (int e = 0; e < C::CS; ++e) {
             if (16 * e + 15 < K) { vc[e] = 0.0; continue; }   // every row of this slot is above the pivot
             const int r = l16 + 16 * e;
-            const double xl = (r > K && r < C::M) ? xb[(r & 1) * HR + (r >> 1)] : 0.0;
+            const double xl = (r > K && r < C::M) ? xc[8 * e] : 0.0;
             vc[e] = (r == K) ? vk : xl;
             part = fma(vc[e], cr[e], part);
         }
@@ -146,22 +189,25 @@ __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], doub
 
 template <int K, int KEND>
 struct QrLoop {
-    static __device__ __forceinline__ void run(double (&a)[Hex8::SLOTS][Hex8::HR], double (&cr)[Hex8::CS], double *xb,
+    static __device__ __forceinline__ void run(double (&a)[Hex8::SLOTS][Hex8::HR], double (&cr)[Hex8::CS],
+                                               double (&rinv)[Hex8::SLOTS], double *xb, lds_f64 *xh, const lds_f64 *xc,
                                                int l8, int h, int l16) {
-        qr_step<K>(a, cr, xb, l8, h, l16);
-        QrLoop<K + 1, KEND>::run(a, cr, xb, l8, h, l16);
+        qr_step<K>(a, cr, rinv, xb, xh, xc, l8, h, l16);
+        QrLoop<K + 1, KEND>::run(a, cr, rinv, xb, xh, xc, l8, h, l16);
     }
 };
 template <int KEND>
 struct QrLoop<KEND, KEND> {
-    static __device__ __forceinline__ void run(double (&)[Hex8::SLOTS][Hex8::HR], double (&)[Hex8::CS], double *, int, int, int) {}
+    static __device__ __forceinline__ void run(double (&)[Hex8::SLOTS][Hex8::HR], double (&)[Hex8::CS], double (&)[Hex8::SLOTS],
+                                               double *, lds_f64 *, const lds_f64 *, int, int, int) {}
 };
 
 // Back-substitution R y = b, row J (compile-time).  R(J, j) sits in lane (j % 8, J % 2) at local row J / 2,
 // slot j / 8; b_J in cr[J / 16] of lane J % 16; y_j is kept in both lanes of column lane j % 8.
 template <int J>
 __device__ __forceinline__ void back_step(const double (&a)[Hex8::SLOTS][Hex8::HR], const double (&cr)[Hex8::CS],
-                                          double (&y)[Hex8::SLOTS], int l8, int h, int l16) {
+                                          const double (&rinv)[Hex8::SLOTS], double (&y)[Hex8::SLOTS], int l8, int h,
+                                          int l16) {
     using C = Hex8;
     constexpr int QJ = J / 8, LJ = J % 8, HJ = J % 2, PJ = J / 2;
     double part = (l16 == J % 16) ? -cr[J / 16] : 0.0;
@@ -173,37 +219,37 @@ __device__ __forceinline__ void back_step(const double (&a)[Hex8::SLOTS][Hex8::H
         }
     }
     const double tot = group16_sum(part);       // sum_{j > J} R(J,j) y_j - b_J
-    const double yj = -tot / a[QJ][PJ];         // meaningful in lane (LJ, HJ)
-    const double yp = partner(yj);
-    y[QJ] = (l8 == LJ) ? ((h == HJ) ? yj : yp) : y[QJ];
+    const double yj = -tot * rinv[QJ];          // meaningful in the two lanes of column lane LJ
+    y[QJ] = (l8 == LJ) ? yj : y[QJ];
 }
 
 template <int J>
 struct BackLoop {
     static __device__ __forceinline__ void run(const double (&a)[Hex8::SLOTS][Hex8::HR], const double (&cr)[Hex8::CS],
-                                               double (&y)[Hex8::SLOTS], int l8, int h, int l16) {
-        back_step<J>(a, cr, y, l8, h, l16);
-        BackLoop<J - 1>::run(a, cr, y, l8, h, l16);
+                                               const double (&rinv)[Hex8::SLOTS], double (&y)[Hex8::SLOTS], int l8, int h,
+                                               int l16) {
+        back_step<J>(a, cr, rinv, y, l8, h, l16);
+        BackLoop<J - 1>::run(a, cr, rinv, y, l8, h, l16);
     }
 };
 template <>
 struct BackLoop<-1> {
     static __device__ __forceinline__ void run(const double (&)[Hex8::SLOTS][Hex8::HR], const double (&)[Hex8::CS],
-                                               double (&)[Hex8::SLOTS], int, int, int) {}
+                                               const double (&)[Hex8::SLOTS], double (&)[Hex8::SLOTS], int, int, int) {}
 };
 
 __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                                int32_t count, int add_neumann,
                                                                double *__restrict__ out, double *__restrict__ nws) {
     using C = Hex8;
-    constexpr int NE = C::NE, NIF = C::NIF, M = C::M, NA = C::NA, SLOTS = C::SLOTS, HR = C::HR, FR = C::FR;
+    constexpr int NE = C::NE, NIF = C::NIF, M = C::M, NA = C::NA, SLOTS = C::SLOTS, HR = C::HR;
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int l16 = lane & 15, l8 = lane & 7, h = (lane >> 3) & 1, grp = lane >> 4;
     constexpr int GPW = C::NODES_PER_WAVE;
     double *node_lds = smem + ((size_t)wave * GPW + grp) * C::NODE_DOUBLES;
-    double *faces = node_lds;                              // [NIF][FR]
-    double *xb = faces + NIF * FR;                         // [2][HR] published column, by half
+    double *stage = node_lds;                              // [8][M] columns of the slot being assembled
+    double *xb = stage + C::STAGE;                         // [2][HR] published column, by half
     int32_t *cells = reinterpret_cast<int32_t *>(xb + M);  // [NE]
     double *prod = xb + M + NE / 2;                        // [NA]
 
@@ -216,12 +262,25 @@ __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const
         const int32_t eb = g.esup_ptr[p], fb = g.fsup_ptr[p];
         const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1],
                      xv2 = g.coords[3 * (size_t)p + 2];
-        if (l16 < NE) cells[l16] = g.esup[eb + l16];
+        // lane l16 < 8 is cell l16 of the node: its row (x_K - x_v) (gls.pyx:269-277).  Lanes 8..15 redo
+        // cell l16 - 8 (no zero-initialised merge values: those get hoisted out of the node loop as registers)
+        double dc[3];
+        {
+            const int32_t c = g.esup[eb + l8];
+            if (l16 < NE) cells[l16] = c;
+            dc[0] = g.centroids[3 * (size_t)c + 0] - xv0;
+            dc[1] = g.centroids[3 * (size_t)c + 1] - xv1;
+            dc[2] = g.centroids[3 * (size_t)c + 2] - xv2;
+        }
         lds_sync();
-        // ---- face records: B_a = [K_a N; T1; tau T2], B_b = [K_b N; T1; tau T2]  (gls.pyx:293-321) ------
-        if (l16 < NIF) {
-            const int s = l16;
-            const size_t f = (size_t)g.fsup[fb + s];
+        // lane l16 < 12 is face l16 of the node (lanes 12..15 redo face 11 and write nothing):
+        // B_a = [K_a N; T1; tau T2], B_b = [K_b N; T1; tau T2] (gls.pyx:293-321), kept in registers until
+        // the three slots have been staged.  B_b differs from B_a only in its first row.
+        double Ba[3][3], Bb0[3];   // Ba[e][t]
+        int Ia = 0, Ib = 0;
+        {
+            const int sf = l16 < NIF ? l16 : NIF - 1;
+            const size_t f = (size_t)g.fsup[fb + sf];
             const int ca = g.face_cells[2 * f], cb = g.face_cells[2 * f + 1];
             const double N0 = g.face_normal[3 * f + 0], N1 = g.face_normal[3 * f + 1], N2 = g.face_normal[3 * f + 2];
             const double T0 = xv0 - g.face_center[3 * f + 0], T1 = xv1 - g.face_center[3 * f + 1],
@@ -231,66 +290,75 @@ __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const
             double eta = 0.0;
             eta = da > eta ? da : eta;
             eta = db > eta ? db : eta;
-            const double tj = pow(sqrt(U0 * U0 + U1 * U1 + U2 * U2), -eta);
+            // tau = |T_sj2|^(-eta) (gls.pyx:314): for a positive base pow(u, -eta) = exp(-eta log u)
+            const double un = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
+            const double tj = eta == 0.0 ? 1.0 : exp(-eta * log(un));
             const double *Ka = g.perm + 9 * (size_t)ca, *Kb = g.perm + 9 * (size_t)cb;
-            int Ia = 0, Ib = 0;
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 const int cq = cells[q];
                 Ia = cq == ca ? q : Ia;
                 Ib = cq == cb ? q : Ib;
             }
-            double *rec = faces + s * FR;
-            reinterpret_cast<int32_t *>(rec)[0] = Ia;
-            reinterpret_cast<int32_t *>(rec)[1] = Ib;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                rec[2 + c] = Ka[c * 3 + 0] * N0 + Ka[c * 3 + 1] * N1 + Ka[c * 3 + 2] * N2;
-                rec[11 + c] = Kb[c * 3 + 0] * N0 + Kb[c * 3 + 1] * N1 + Kb[c * 3 + 2] * N2;
+            for (int t = 0; t < 3; ++t) {
+                Ba[0][t] = Ka[t * 3 + 0] * N0 + Ka[t * 3 + 1] * N1 + Ka[t * 3 + 2] * N2;   // (K_a N)_t
+                Bb0[t] = Kb[t * 3 + 0] * N0 + Kb[t * 3 + 1] * N1 + Kb[t * 3 + 2] * N2;
             }
-            rec[5] = T0; rec[6] = T1; rec[7] = T2;
-            rec[14] = T0; rec[15] = T1; rec[16] = T2;
-            rec[8] = tj * U0; rec[9] = tj * U1; rec[10] = tj * U2;
-            rec[17] = tj * U0; rec[18] = tj * U1; rec[19] = tj * U2;
+            Ba[1][0] = T0; Ba[1][1] = T1; Ba[1][2] = T2;
+            Ba[2][0] = tj * U0; Ba[2][1] = tj * U1; Ba[2][2] = tj * U2;
         }
-        lds_sync();
-        // ---- this lane's entries: columns j = l8 + 8 q <-> (cell i = j / 3, component t = j % 3),
-        //      rows r = 2 rl + h -------------------------------------------------------------------------
+        // ---- deal the matrix into registers, one slot (8 columns) at a time through the staging buffer.
+        //      Column j = 3 i + t (cell i, component t) -> slot j / 8, column lane j % 8; this lane then keeps
+        //      rows 2 rl + h of columns l8, l8 + 8, l8 + 16.  [-B_a | +B_b] per face, gls.pyx:340-356. -----------
         double a[SLOTS][HR], cr[C::CS], dsave[SLOTS], y[SLOTS];
-        int ci[SLOTS], ct[SLOTS];
+        lds_f64 *stage_l = lds_base(stage + l16);
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
-            const int j = l8 + 8 * q;
-            ci[q] = j / 3;
-            ct[q] = j - 3 * ci[q];
-            const double xvt = ct[q] == 0 ? xv0 : (ct[q] == 1 ? xv1 : xv2);
-            dsave[q] = g.centroids[3 * (size_t)cells[ci[q]] + ct[q]] - xvt;   // (x_K - x_v)_t, gls.pyx:269-277
-            y[q] = 0.0;
-        }
 #pragma unroll
-        for (int rl = 0; rl < HR; ++rl) {
-            const int r = 2 * rl + h;
-            if (2 * rl + 1 < NE) {               // both halves of this local row are cell rows
+            for (int i = 0; i < C::STAGE / 16; ++i) stage_l[16 * i] = 0.0;
+            lds_sync();
+            if (l16 < NE) {
 #pragma unroll
-                for (int q = 0; q < SLOTS; ++q) a[q][rl] = (r == ci[q]) ? dsave[q] : 0.0;
-            } else {                             // face rows: r = NE + 3 s + e  ->  [-B_a | +B_b], gls.pyx:340-356
-                const int fr = r - NE, s = (fr * 43) >> 7, e = fr - 3 * s;   // fr / 3, exact for fr < 100
-                const double *rec = faces + s * FR;
-                const int Ia = reinterpret_cast<const int32_t *>(rec)[0], Ib = reinterpret_cast<const int32_t *>(rec)[1];
-#pragma unroll
-                for (int q = 0; q < SLOTS; ++q) {
-                    const bool isa = Ia == ci[q], isb = Ib == ci[q];
-                    const double v = rec[(isa ? 2 : 11) + 3 * e + ct[q]];
-                    a[q][rl] = isa ? -v : (isb ? v : 0.0);
+                for (int t = 0; t < 3; ++t) {
+                    const int j = 3 * l16 + t;
+                    if ((j >> 3) == q) stage[(j & 7) * M + l16] = dc[t];
                 }
             }
+            if (l16 < NIF) {
+                const int row = NE + 3 * l16;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int ja = 3 * Ia + t, jb = 3 * Ib + t;
+                    if ((ja >> 3) == q) {
+                        double *col = stage + (ja & 7) * M + row;
+                        col[0] = -Ba[0][t]; col[1] = -Ba[1][t]; col[2] = -Ba[2][t];
+                    }
+                    if ((jb >> 3) == q) {
+                        double *col = stage + (jb & 7) * M + row;
+                        col[0] = Bb0[t]; col[1] = Ba[1][t]; col[2] = Ba[2][t];
+                    }
+                }
+            }
+            lds_sync();
+            const lds_f64 *mine = lds_base(stage + l8 * M + h);
+#pragma unroll
+            for (int rl = 0; rl < HR; ++rl) a[q][rl] = mine[2 * rl];
+            {   // the column's own cell-row entry d_i[t] (needed again for r_i = 1 - d_i . y_i): row i = j / 3
+                const int j = l8 + 8 * q, i = (j * 43) >> 7;
+                dsave[q] = stage[l8 * M + i];
+            }
+            y[q] = 0.0;
+            lds_sync();
         }
 #pragma unroll
         for (int e = 0; e < C::CS; ++e) cr[e] = (l16 + 16 * e < NE) ? 1.0 : 0.0;   // c = 1 on the cell rows
-        lds_sync();
 
-        QrLoop<0, NA>::run(a, cr, xb, l8, h, l16);
-        BackLoop<NA - 1>::run(a, cr, y, l8, h, l16);
+        double rinv[SLOTS];
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) rinv[q] = 0.0;
+        QrLoop<0, NA>::run(a, cr, rinv, xb, lds_base(xb + h * HR), lds_base(xb + (l16 & 1) * HR + (l16 >> 1)), l8, h, l16);
+        BackLoop<NA - 1>::run(a, cr, rinv, y, l8, h, l16);
 
         // ---- r_i = 1 - d_i . y_i on the cell rows, r.r = |c~(NA:M)|^2, weights = r_i / (r.r) -------------
         if (h == 0) {
