@@ -31,6 +31,8 @@
 // interior node of a hexahedron mesh (M = 44, 24 + 1 columns).  Everything else runs in kernels_gls.hip.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_grid.hpp"
 #include "launch.hpp"
 
@@ -64,6 +66,8 @@ __device__ __forceinline__ double group16_sum(double v) {
 // PAIR of rows out of the node loop (measured: ~100 VGPRs of addresses, spilled).  A laundered pointer is
 // an opaque base, so every access below is that base + a small compile-time offset.
 typedef __attribute__((address_space(3))) double lds_f64;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f64x2 lds_f64x2;
 __device__ __forceinline__ lds_f64 *lds_base(double *p) {
     lds_f64 *q = (lds_f64 *)p;
     asm volatile("" : "+v"(q));
@@ -95,6 +99,13 @@ __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// tau = |T_sj2|^(-eta) (gls.pyx:314); for a positive base pow(u, -eta) = exp(-eta log u).  Kept out of line:
+// inlined, the ~40 VGPRs of exp / log polynomial coefficients are hoisted out of the node loop and stay
+// live across the whole QR, which pushes the kernel into scratch.
+__device__ __attribute__((noinline)) double face_tau(double un, double eta) {
+    return eta == 0.0 ? 1.0 : exp(-eta * log(un));
+}
+
 struct Hex8 {
     static constexpr int NE = 8, NIF = 12;
     static constexpr int M = NE + 3 * NIF;   // 44 rows
@@ -103,40 +114,59 @@ struct Hex8 {
     static constexpr int HR = M / 2;         // 22 local rows per half
     static constexpr int CS = (M + 15) / 16; // 3 rows of c per lane
     static constexpr int STAGE = 8 * M;      // staging buffer: the 8 columns of one register slot, column-major
-    static constexpr int NODE_DOUBLES = STAGE + M + NE / 2 + NA;
+    static constexpr int HRP = 24;           // padded half length of the published column (rows up to 47 exist, zero)
+    static constexpr int XB = 2 * HRP + 2;   // published column by half + the pivot entry alpha
+    static constexpr int NODE_DOUBLES = STAGE + XB + NE / 2 + NA + 64;   // + 4 dump words per lane (branch-free scatter)
     static constexpr int LANES = 16, NODES_PER_WAVE = 4;
 };
 
 // One Householder step K (compile-time).  l8: column lane, h: row half, l16 = 8 h + l8.
+//
+// The published column lives in xb as two halves of HRP entries (row r -> half r % 2, slot r / 2).  The
+// owner writes x = column K BELOW the pivot and ZERO at the pivot and at the row above it, so by
+// induction every entry of the buffer at rows <= K is zero and readers need no masks: the pivot row drops
+// out of the norm and of the dot products by itself.  The pivot entry alpha travels in its own slot.
+// xh = xb + h * HRP (this lane's half), xc = xb + (l16 & 1) * HRP + (l16 >> 1) (rows l16 + 16 e): every LDS
+// access is a laundered base + compile-time offset (see lds_base).
 template <int K>
 __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], double (&cr)[Hex8::CS], double (&rinv)[Hex8::SLOTS],
-                                        double *xb, lds_f64 *xh, const lds_f64 *xc, int l8, int h, int l16) {
-    // xh = xb + h * HR (this lane's half of the published column), xc = xb + (l16 & 1) * HR + (l16 >> 1) (the
-    // rows l16 + 16 e of it): every LDS access below is pointer + compile-time offset, which the DS
-    // instructions take as an immediate -- indexing xb[h * HR + rl] instead costs one VGPR per address.
+                                        lds_f64 *xh, const lds_f64 *xc, lds_f64 *xalpha, int l8, int h, int l16) {
     using C = Hex8;
     constexpr int QK = K / 8, LK = K % 8, HP = K % 2, PL = K / 2, RL0 = (K + 1) / 2, HR = C::HR;
     const bool owner = (l8 == LK);
     const bool pivot_half = (h == HP);
     if (owner) {
+        // local row PL is the pivot row (pivot half), row K - 1 (K odd, other half) or row K + 1 (K even, other half)
+        xh[PL] = (HP == 0 && !pivot_half) ? a[QK][PL] : 0.0;
 #pragma unroll
-        for (int rl = PL; rl < HR; ++rl) xh[rl] = a[QK][rl];
+        for (int rl = PL + 1; rl < HR; ++rl) xh[rl] = a[QK][rl];
+        if (pivot_half) xalpha[0] = a[QK][PL];
     }
     lds_sync();
-    // pass 1 over this lane's half of the published column (rows strictly below the pivot): |x|^2 and the
-    // dot products with the lane's own columns.  x is NOT kept in registers between the passes: 22 more
-    // doubles would push the kernel past 256 VGPRs into scratch (measured: 25 GB of spill writes per launch).
-    const double alpha = xb[HP * HR + PL];
+    // pass 1 over this lane's half of the published column: |x|^2 and the dot products with the lane's own
+    // columns.  The LDS pipe is shared by the 4 SIMDs of a CU and this kernel is bound by it (the publish
+    // costs ~13 LDS cycles per ds_write2_b64 whatever the exec mask), so x is read ONCE, as 16-byte
+    // ds_read_b128 where the pair is aligned, and kept in registers for pass 2.
+    const double alpha = xalpha[0];
+    double x[HR];
+    {
+        constexpr int RA = RL0 + (RL0 & 1);          // first even local row >= RL0
+        if (RL0 & 1) x[RL0] = xh[RL0];
+#pragma unroll
+        for (int rl = RA; rl < HR; rl += 2) {
+            const f64x2 v = *reinterpret_cast<const lds_f64x2 *>(xh + rl);
+            x[rl] = v.x;
+            x[rl + 1] = v.y;
+        }
+    }
     double ss = 0.0, d[C::SLOTS];
 #pragma unroll
     for (int q = 0; q < C::SLOTS; ++q) d[q] = 0.0;
 #pragma unroll
     for (int rl = RL0; rl < HR; ++rl) {
-        double xr = xh[rl];
-        if (HP == 0 && rl == PL) xr = (h == 0) ? 0.0 : xr;   // K even: local row PL of half 0 IS the pivot row
-        ss = fma(xr, xr, ss);
+        ss = fma(x[rl], x[rl], ss);
 #pragma unroll
-        for (int q = QK; q < C::SLOTS; ++q) d[q] = fma(xr, a[q][rl], d[q]);
+        for (int q = QK; q < C::SLOTS; ++q) d[q] = fma(x[rl], a[q][rl], d[q]);
     }
     ss += partner(ss);
     // beta = -sign(alpha) |(alpha, x)| (dlarfg);  H = I - g v v^T,  v = (alpha - beta, x),
@@ -150,56 +180,53 @@ __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], doub
     const double gk = live ? gden : 0.0;
     const double rinv_k = live ? -(gden * vk) : gden;                    // 1 / R(K,K), for the back-substitution
     if (owner) rinv[QK] = rinv_k;
-    if (owner && pivot_half) a[QK][PL] = beta;   // R(K,K); the rest of this column is dead from here on
+    const double vkh = pivot_half ? vk : 0.0;                            // the pivot entry of v, in the half that holds row K
     double gw[C::SLOTS];
 #pragma unroll
     for (int q = QK; q < C::SLOTS; ++q) {
-        const bool act = (q > QK) || (l8 > LK);   // column j = l8 + 8 q is to the right of K
-        double w = pivot_half ? fma(vk, a[q][PL], d[q]) : d[q];
+        double w = fma(vkh, a[q][PL], d[q]);
         w += partner(w);
-        gw[q] = act ? -(gk * w) : 0.0;
-        if (pivot_half) a[q][PL] = fma(gw[q], vk, a[q][PL]);
+        w = -(gk * w);
+        if (q == QK) w = (l8 > LK) ? w : 0.0;     // in slot QK only the columns to the right of K are updated
+        gw[q] = w;
+        a[q][PL] = fma(w, vkh, a[q][PL]);        // the pivot row (vkh = 0 elsewhere: no change)
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // pass 2 re-reads x from LDS
 #pragma unroll
     for (int rl = RL0; rl < HR; ++rl) {
-        double xr = xh[rl];
-        if (HP == 0 && rl == PL) xr = (h == 0) ? 0.0 : xr;
 #pragma unroll
-        for (int q = QK; q < C::SLOTS; ++q) a[q][rl] = fma(gw[q], xr, a[q][rl]);
+        for (int q = QK; q < C::SLOTS; ++q) a[q][rl] = fma(gw[q], x[rl], a[q][rl]);
     }
-    // the last column c, dealt by rows: lane l16 holds rows l16, l16 + 16, l16 + 32
+    // the last column c, dealt by rows: lane l16 holds rows l16, l16 + 16, l16 + 32 (rows 44..47 are padding: 0)
     {
-        double vc[C::CS], part = 0.0;
+        constexpr int E0 = K / 16;                 // slots below E0 hold only rows above the pivot
+        const double vkc = (l16 == K % 16) ? vk : 0.0;
+        double xl[C::CS], part = vkc * cr[E0];
 #pragma unroll
-        for (int e = 0; e < C::CS; ++e) {
-            if (16 * e + 15 < K) { vc[e] = 0.0; continue; }   // every row of this slot is above the pivot
-            const int r = l16 + 16 * e;
-            const double xl = (r > K && r < C::M) ? xc[8 * e] : 0.0;
-            vc[e] = (r == K) ? vk : xl;
-            part = fma(vc[e], cr[e], part);
+        for (int e = E0; e < C::CS; ++e) {
+            xl[e] = xc[8 * e];
+            part = fma(xl[e], cr[e], part);
         }
         const double gwc = -(gk * group16_sum(part));
+        cr[E0] = fma(gwc, vkc, cr[E0]);
 #pragma unroll
-        for (int e = 0; e < C::CS; ++e) cr[e] = fma(gwc, vc[e], cr[e]);
+        for (int e = E0; e < C::CS; ++e) cr[e] = fma(gwc, xl[e], cr[e]);
     }
     lds_sync();                          // the next step overwrites xb
-    __builtin_amdgcn_sched_barrier(0);   // keep the steps apart (register pressure)
 }
 
 template <int K, int KEND>
 struct QrLoop {
     static __device__ __forceinline__ void run(double (&a)[Hex8::SLOTS][Hex8::HR], double (&cr)[Hex8::CS],
-                                               double (&rinv)[Hex8::SLOTS], double *xb, lds_f64 *xh, const lds_f64 *xc,
+                                               double (&rinv)[Hex8::SLOTS], lds_f64 *xh, const lds_f64 *xc, lds_f64 *xalpha,
                                                int l8, int h, int l16) {
-        qr_step<K>(a, cr, rinv, xb, xh, xc, l8, h, l16);
-        QrLoop<K + 1, KEND>::run(a, cr, rinv, xb, xh, xc, l8, h, l16);
+        qr_step<K>(a, cr, rinv, xh, xc, xalpha, l8, h, l16);
+        QrLoop<K + 1, KEND>::run(a, cr, rinv, xh, xc, xalpha, l8, h, l16);
     }
 };
 template <int KEND>
 struct QrLoop<KEND, KEND> {
     static __device__ __forceinline__ void run(double (&)[Hex8::SLOTS][Hex8::HR], double (&)[Hex8::CS], double (&)[Hex8::SLOTS],
-                                               double *, lds_f64 *, const lds_f64 *, int, int, int) {}
+                                               lds_f64 *, const lds_f64 *, lds_f64 *, int, int, int) {}
 };
 
 // Back-substitution R y = b, row J (compile-time).  R(J, j) sits in lane (j % 8, J % 2) at local row J / 2,
@@ -238,6 +265,7 @@ struct BackLoop<-1> {
                                                const double (&)[Hex8::SLOTS], double (&)[Hex8::SLOTS], int, int, int) {}
 };
 
+template <int DBG>
 __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                                int32_t count, int add_neumann,
                                                                double *__restrict__ out, double *__restrict__ nws) {
@@ -249,12 +277,17 @@ __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const
     constexpr int GPW = C::NODES_PER_WAVE;
     double *node_lds = smem + ((size_t)wave * GPW + grp) * C::NODE_DOUBLES;
     double *stage = node_lds;                              // [8][M] columns of the slot being assembled
-    double *xb = stage + C::STAGE;                         // [2][HR] published column, by half
-    int32_t *cells = reinterpret_cast<int32_t *>(xb + M);  // [NE]
-    double *prod = xb + M + NE / 2;                        // [NA]
+    double *xb = stage + C::STAGE;                         // [2][HRP] published column by half, then alpha
+    int32_t *cells = reinterpret_cast<int32_t *>(xb + C::XB);  // [NE]
+    double *prod = xb + C::XB + NE / 2;                    // [NA]
 
     const int32_t n_groups = (count + GPW - 1) / GPW;
+    unsigned long long stamps[8];
+    int n_stamp = 0;
+#define NIN_STAMP() do { if (DBG == 3 && n_stamp < 8) { __builtin_amdgcn_sched_barrier(0); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
     for (int32_t wg = blockIdx.x * wpb + wave; wg < n_groups; wg += gridDim.x * wpb) {
+        if (DBG == 3) n_stamp = 0;
+        NIN_STAMP();
         const int32_t idx = wg * GPW + grp;
         const bool valid = idx < count;
         const int32_t sel = valid ? idx : count - 1;
@@ -292,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const
             eta = db > eta ? db : eta;
             // tau = |T_sj2|^(-eta) (gls.pyx:314): for a positive base pow(u, -eta) = exp(-eta log u)
             const double un = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
-            const double tj = eta == 0.0 ? 1.0 : exp(-eta * log(un));
+            const double tj = face_tau(un, eta);
             const double *Ka = g.perm + 9 * (size_t)ca, *Kb = g.perm + 9 * (size_t)cb;
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
@@ -308,39 +341,45 @@ __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const
             Ba[1][0] = T0; Ba[1][1] = T1; Ba[1][2] = T2;
             Ba[2][0] = tj * U0; Ba[2][1] = tj * U1; Ba[2][2] = tj * U2;
         }
+        NIN_STAMP();
         // ---- deal the matrix into registers, one slot (8 columns) at a time through the staging buffer.
         //      Column j = 3 i + t (cell i, component t) -> slot j / 8, column lane j % 8; this lane then keeps
         //      rows 2 rl + h of columns l8, l8 + 8, l8 + 16.  [-B_a | +B_b] per face, gls.pyx:340-356. -----------
         double a[SLOTS][HR], cr[C::CS], dsave[SLOTS], y[SLOTS];
         lds_f64 *stage_l = lds_base(stage + l16);
+        lds_f64 *stage_b = (lds_f64 *)stage;
+        lds_f64 *dump = (lds_f64 *)(prod + NA) + 4 * l16, *dump3 = dump;   // this lane's scratch words: written, never read
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) {
 #pragma unroll
             for (int i = 0; i < C::STAGE / 16; ++i) stage_l[16 * i] = 0.0;
             lds_sync();
-            if (l16 < NE) {
+            if (q == 0) NIN_STAMP();
+            // branch-free scatter: an entry that is not in this slot goes to the lane's dump word instead
+            {
+                const int ic = l16 < NE ? l16 : 0;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const int j = 3 * l16 + t;
-                    if ((j >> 3) == q) stage[(j & 7) * M + l16] = dc[t];
+                    const int j = 3 * ic + t;
+                    const bool on = (l16 < NE) && ((j >> 3) == q);
+                    lds_f64 *dst = on ? stage_b + ((j & 7) * M + ic) : dump;
+                    *dst = dc[t];
                 }
             }
-            if (l16 < NIF) {
-                const int row = NE + 3 * l16;
+            {
+                const int row = NE + 3 * (l16 < NIF ? l16 : 0);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const int ja = 3 * Ia + t, jb = 3 * Ib + t;
-                    if ((ja >> 3) == q) {
-                        double *col = stage + (ja & 7) * M + row;
-                        col[0] = -Ba[0][t]; col[1] = -Ba[1][t]; col[2] = -Ba[2][t];
-                    }
-                    if ((jb >> 3) == q) {
-                        double *col = stage + (jb & 7) * M + row;
-                        col[0] = Bb0[t]; col[1] = Ba[1][t]; col[2] = Ba[2][t];
-                    }
+                    const bool ona = (l16 < NIF) && ((ja >> 3) == q), onb = (l16 < NIF) && ((jb >> 3) == q);
+                    lds_f64 *ca_ = ona ? stage_b + ((ja & 7) * M + row) : dump3;
+                    lds_f64 *cb_ = onb ? stage_b + ((jb & 7) * M + row) : dump3;
+                    ca_[0] = -Ba[0][t]; ca_[1] = -Ba[1][t]; ca_[2] = -Ba[2][t];
+                    cb_[0] = Bb0[t]; cb_[1] = Ba[1][t]; cb_[2] = Ba[2][t];
                 }
             }
             lds_sync();
+            if (q == 0) NIN_STAMP();
             const lds_f64 *mine = lds_base(stage + l8 * M + h);
 #pragma unroll
             for (int rl = 0; rl < HR; ++rl) a[q][rl] = mine[2 * rl];
@@ -350,15 +389,23 @@ __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const
             }
             y[q] = 0.0;
             lds_sync();
+            if (q == 0 || q == 1) NIN_STAMP();
         }
 #pragma unroll
         for (int e = 0; e < C::CS; ++e) cr[e] = (l16 + 16 * e < NE) ? 1.0 : 0.0;   // c = 1 on the cell rows
+#pragma unroll
+        for (int e = 0; e < C::CS; ++e) xb[l16 + 16 * e] = 0.0;                    // published-column buffer starts all zero
+        lds_sync();
 
         double rinv[SLOTS];
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) rinv[q] = 0.0;
-        QrLoop<0, NA>::run(a, cr, rinv, xb, lds_base(xb + h * HR), lds_base(xb + (l16 & 1) * HR + (l16 >> 1)), l8, h, l16);
-        BackLoop<NA - 1>::run(a, cr, rinv, y, l8, h, l16);
+        NIN_STAMP();
+        if (DBG != 1) QrLoop<0, NA>::run(a, cr, rinv, lds_base(xb + h * C::HRP), lds_base(xb + (l16 & 1) * C::HRP + (l16 >> 1)),
+                                         lds_base(xb + 2 * C::HRP), l8, h, l16);
+        if (DBG != 1 && DBG != 2) BackLoop<NA - 1>::run(a, cr, rinv, y, l8, h, l16);
+        NIN_STAMP();
+        if (DBG == 1 || DBG == 2) { double acc = 0; for (int q = 0; q < SLOTS; ++q) for (int rl = 0; rl < HR; ++rl) acc += a[q][rl]; y[0] = acc; }
 
         // ---- r_i = 1 - d_i . y_i on the cell rows, r.r = |c~(NA:M)|^2, weights = r_i / (r.r) -------------
         if (h == 0) {
@@ -388,6 +435,11 @@ __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const
             if (l8 == 0) nws[p] = nwv;
         }
         lds_sync();
+        NIN_STAMP();
+        if (DBG == 3 && blockIdx.x == 0 && threadIdx.x == 0 && wg == (int32_t)(blockIdx.x * wpb + wave) + 3 * (int32_t)(gridDim.x * wpb)) {
+            const int32_t p0 = nodes ? nodes[0] : 0;   // debug build only: 4th pass of wave 0, into the row of its 1st node
+            for (int i = 0; i < n_stamp; ++i) out[g.esup_ptr[p0] + i] = 1.0e6 + (double)(stamps[i] - stamps[0]);
+        }
     }
 }
 
@@ -402,7 +454,14 @@ int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int 
     int64_t blocks = ((int64_t)count + wpb * C::NODES_PER_WAVE - 1) / (wpb * C::NODES_PER_WAVE);
     const int64_t cap = 256 * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(nin_gls_group_kernel, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count,
+    static const int max_blocks = getenv("NIN_GLS_MAX_BLOCKS") ? atoi(getenv("NIN_GLS_MAX_BLOCKS")) : 0;
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    static const int dbg = getenv("NIN_GLS_DEBUG_MODE") ? atoi(getenv("NIN_GLS_DEBUG_MODE")) : 0;
+    if (dbg == 3) hipLaunchKernelGGL(nin_gls_group_kernel<3>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws);
+    else if (dbg == 1) hipLaunchKernelGGL(nin_gls_group_kernel<1>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws);
+    else if (dbg == 2) hipLaunchKernelGGL(nin_gls_group_kernel<2>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws);
+    else
+    hipLaunchKernelGGL(nin_gls_group_kernel<0>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count,
                        add_neumann, out, nws);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
