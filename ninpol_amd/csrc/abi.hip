@@ -379,8 +379,8 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     if (!all && n_targets < 0) return fail(NIN_EINVAL, "negative n_targets");
     int rc = 0;
     if (all) {
-        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, nullptr, (int32_t)P, dev_csr_data, dev_neumann_ws, stream);
-        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, dev_csr_data, dev_neumann_ws, stream);
+        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
+        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
         else {
             rc = launch_gls_hex8(d.v, d.hex8.nodes, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             for (int c = 0; c < kGlsClasses && !rc; ++c) {
@@ -411,8 +411,8 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         HIP_TRY(hipMemcpyAsync(dl, lists[c].data(), lists[c].size() * 4, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));  // the pageable source vector dies with this scope
         const int32_t cnt = (int32_t)lists[c].size();
-        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, dev_csr_data, dev_neumann_ws, stream);
-        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, dev_csr_data, dev_neumann_ws, stream);
+        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
+        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_gls_hex8(d.v, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else rc = launch_gls_class(d.v, dl, cnt, d.gls[c].lds_bytes, d.gls[c].rows_per_lane, add_neumann, dev_csr_data,
                                    dev_neumann_ws, d.gls_scratch, d.gls_scratch_stride, d.gls_scratch_slots, stream);
@@ -497,8 +497,8 @@ int64_t nin_algorithmic_bytes(const nin_grid *g, int method) {
 }
 
 const char *nin_kernel_name(int method) {
-    if (method == NIN_METHOD_IDW) return "nin_idw_kernel";
-    if (method == NIN_METHOD_LS) return "nin_ls_kernel";
+    if (method == NIN_METHOD_IDW) return "nin_rows_kernel<0>";
+    if (method == NIN_METHOD_LS) return "nin_rows_kernel<1>";
     return kernel_name_gls_hex8();   // dominant on hexahedron meshes; kernel_name_gls() covers the other nodes
 }
 

@@ -9,9 +9,10 @@
 namespace nin {
 
 // all return 0 or a negative NIN_E* code; launches are asynchronous on `stream`
-int launch_idw(const GridView &g, const int32_t *targets, int32_t n_targets, double *out, double *nws,
+// targets == nullptr: all nodes 0 .. n_targets-1 (the wave-cooperative kernel); mx_row = MX_ELEMENTS_PER_POINT
+int launch_idw(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, double *out, double *nws,
                hipStream_t stream);
-int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, double *out, double *nws,
+int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, double *out, double *nws,
               hipStream_t stream);
 // one GLS size class: `nodes` lists the class members (device), lds_bytes is per wave
 int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes,

@@ -1,0 +1,157 @@
+"""CPU-side tests of the product's host layer (no GPU needed): the C-ABI library loads and exports
+everything include/ninpol_amd.h declares, the native host Grid reproduces the reference's arrays bit
+for bit (golden fixtures + live oracle), the Interpolator mirrors the reference's tables, errors and
+quirks, and the weight kernels refuse to run without a device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from ninpol_amd import mesh as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ninpol_amd import build as nbuild
+    nbuild.build()
+    from ninpol_amd import _lib
+    return _lib
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "ninpol_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(nin_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 15
+    L = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/ninpol_amd.h but not exported"
+    assert set(declared) == set(lib.EXPORTS)
+    assert lib.load().nin_version().decode().startswith("ninpol_amd")
+
+
+@pytest.mark.parametrize("case", util.GOLDEN_CASES)
+def test_host_grid_matches_golden(lib, case):
+    import ninpol_amd
+    mesh, z = util.load_golden(case)
+    I = ninpol_amd.Interpolator(build_edges=True)
+    I.load_mesh(mesh_obj=mesh)
+    util.assert_grid_equal(I.grid, z)
+    np.testing.assert_array_equal(I.cells_data, z["cells_data"])
+    np.testing.assert_array_equal(I.points_data, z["points_data"])
+    assert list(I.variable_to_index["cells"]) == [str(s) for s in z["cells_vars"]]
+    assert list(I.variable_to_index["points"]) == [str(s) for s in z["points_vars"]]
+    for k in util.GRID_ARRAYS:
+        assert getattr(I.grid, k).dtype in (np.int64, np.float64)
+
+
+def test_host_grid_matches_oracle_large_and_threads(lib, oracle_lib):
+    import ninpol_amd
+    mesh = M.mixed_mesh(14, 9, 8, jitter=0.1, seed=6)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0))
+    o = oracle_lib.OracleInterpolator("port", threads=2)
+    o.load_mesh(mesh)
+    for nt in (1, 3, 8):
+        I = ninpol_amd.Interpolator(num_threads=nt)
+        I.load_mesh(mesh_obj=mesh)
+        for k in util.GRID_SCALARS:
+            assert getattr(I.grid, k) == getattr(o.grid, k), k
+        for k in util.GRID_ARRAYS:
+            np.testing.assert_array_equal(getattr(I.grid, k), getattr(o.grid, k), err_msg=k)
+
+
+def test_edges_match_reference(lib, oracle_lib):
+    """build_edges=True: inedel / inpoed / n_edges, including the reference's hash-keyed numbering."""
+    if not oracle_lib.have_reference():
+        pytest.skip("oracle/_ref not built")
+    import ninpol_amd
+    mesh = M.mixed_mesh(6, 4, 4, jitter=0.1, seed=2)
+    M.attach_fields(mesh, "u")
+    args = oracle_lib.process_mesh(mesh)
+    drv = oracle_lib._ref_driver()
+    ref = drv.build_grid(*args, np.ascontiguousarray(mesh.points), 1).get_data()
+    I = ninpol_amd.Interpolator(build_edges=True)
+    I.load_mesh(mesh_obj=mesh)
+    mine = I.grid.get_data()
+    assert sorted(mine) == sorted(ref)
+    for k in ref:
+        np.testing.assert_array_equal(np.asarray(mine[k]), np.asarray(ref[k]), err_msg=k)
+
+
+def test_reference_errors_and_quirks(lib):
+    import ninpol_amd
+    I = ninpol_amd.Interpolator()
+    with pytest.raises(ValueError, match="Filename for the mesh or meshio.Mesh object must be provided."):
+        I.load_mesh()
+    with pytest.raises(ValueError, match="Grid not initialized. Please load a mesh first."):
+        I.interpolate("u", "gls")
+    assert list(I.supported_methods) == ["gls", "idw", "ls"]
+    mesh = M.hex_mesh(3)
+    M.attach_fields(mesh, "u")
+    mesh.cell_data["vec"] = [np.zeros((27, 3))]
+    I.load_mesh(mesh_obj=mesh)
+    with pytest.raises(ValueError, match=r"Method 'foo' not supported. Supported methods are: \['gls', 'idw', 'ls'\]"):
+        I.interpolate("u", "foo")
+    with pytest.raises(ValueError, match="Variable 'nope' not found in cells data. Point -> Cell interpolation not supported yet."):
+        I.interpolate("nope", "idw")
+    with pytest.raises(ValueError, match="Variable 'vec' has more than one dimension. Vector data not supported yet."):
+        I.interpolate("vec", "idw")
+    with pytest.raises(ValueError, match="Invalid shape in axis 0: 0."):
+        I.grid.get_data()
+    with pytest.raises(ValueError, match="not found in cells data"):
+        I.get_data("cells", np.arange(3), "nope")
+    assert I.get_data("cells", np.arange(3), "u").shape == (3,)
+    d = I.get_dict()
+    assert list(d["variable_to_index"]["cells"]) == ["permeability", "diff_mag", "u", "vec"]
+    assert d["cells_data"].shape == (4, 27 * 9)
+    # diff_mag as the reference computes it: (1 - 3 / tr K)^2 (cdivision quirk, see test_kat.py)
+    K = mesh.cell_data["permeability"][0].reshape(-1, 3, 3)
+    np.testing.assert_array_equal(I.get_data("cells", np.arange(27), "diff_mag"),
+                                  (1 - (3 * np.ones(27)) / np.trace(K, axis1=1, axis2=2)) ** 2)
+    with pytest.raises(ValueError, match="The number of elements must be greater than 0."):
+        ninpol_amd.Grid(3, 0, 8, *[np.zeros(1)] * 6, np.zeros((0, 8)), np.zeros(0), coords=np.zeros((8, 3)))
+
+
+def test_load_face_data(lib):
+    import ninpol_amd
+    mesh = M.hex_mesh(2)
+    M.attach_fields(mesh, "u")
+    I = ninpol_amd.Interpolator()
+    I.load_mesh(mesh_obj=mesh)
+    F = I.grid.n_faces
+    vals = np.arange(F, dtype=float)
+    I.load_face_data({"flux": vals})
+    np.testing.assert_array_equal(I.faces_data[0], vals)
+    perm = np.random.default_rng(0).permutation(F)
+    I.load_face_data({"flux": vals}, face_connectivity=I.grid.inpofa[perm])
+    np.testing.assert_array_equal(I.faces_data[I.variable_to_index["faces"]["flux"]], vals[perm])
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU the hot path must fail loudly (NIN_ENODEVICE), never compute on the host."""
+    import ninpol_amd
+    if lib.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the -m gpu tests")
+    mesh = M.hex_mesh(3)
+    M.attach_fields(mesh, "u")
+    I = ninpol_amd.Interpolator()
+    I.load_mesh(mesh_obj=mesh)
+    with pytest.raises(lib.NinpolError) as ei:
+        I.interpolate("u", "idw")
+    assert ei.value.code == lib.NIN_ENODEVICE
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ninpol_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                if re.search(r"ninpol_oracle|oracle/|libninpol_oracle|ninpol_ref_driver", text):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
