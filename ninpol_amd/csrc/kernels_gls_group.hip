@@ -113,10 +113,11 @@ struct Hex8 {
     static constexpr int SLOTS = NA / 8;     // 3 columns per lane
     static constexpr int HR = M / 2;         // 22 local rows per half
     static constexpr int CS = (M + 15) / 16; // 3 rows of c per lane
-    static constexpr int STAGE = 8 * M;      // staging buffer: the 8 columns of one register slot, column-major
+    static constexpr int STAGE = NA * M;     // staging buffer: the whole M x NA system, column-major (one wave per SIMD
+                                             // leaves the LDS room: 4 waves x 4 nodes x 9.2 KB = 147 KB of the CU's 160)
     static constexpr int HRP = 24;           // padded half length of the published column (rows up to 47 exist, zero)
     static constexpr int XB = 2 * HRP + 2;   // published column by half + the pivot entry alpha
-    static constexpr int NODE_DOUBLES = STAGE + XB + NE / 2 + NA + 64;   // + 4 dump words per lane (branch-free scatter)
+    static constexpr int NODE_DOUBLES = STAGE + XB + NE / 2 + NA;
     static constexpr int LANES = 16, NODES_PER_WAVE = 4;
 };
 
@@ -266,7 +267,7 @@ struct BackLoop<-1> {
 };
 
 template <int DBG>
-__global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const int32_t *__restrict__ nodes,
+__global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                                int32_t count, int add_neumann,
                                                                double *__restrict__ out, double *__restrict__ nws) {
     using C = Hex8;
@@ -348,48 +349,38 @@ __global__ __launch_bounds__(256, 2) void nin_gls_group_kernel(GridView g, const
         double a[SLOTS][HR], cr[C::CS], dsave[SLOTS], y[SLOTS];
         lds_f64 *stage_l = lds_base(stage + l16);
         lds_f64 *stage_b = (lds_f64 *)stage;
-        lds_f64 *dump = (lds_f64 *)(prod + NA) + 4 * l16, *dump3 = dump;   // this lane's scratch words: written, never read
-#pragma unroll
-        for (int q = 0; q < SLOTS; ++q) {
+        {
 #pragma unroll
             for (int i = 0; i < C::STAGE / 16; ++i) stage_l[16 * i] = 0.0;
             lds_sync();
-            if (q == 0) NIN_STAMP();
-            // branch-free scatter: an entry that is not in this slot goes to the lane's dump word instead
-            {
-                const int ic = l16 < NE ? l16 : 0;
+            NIN_STAMP();
+            if (l16 < NE) {          // cell row l16: (x_K - x_v) on its own three columns
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int j = 3 * ic + t;
-                    const bool on = (l16 < NE) && ((j >> 3) == q);
-                    lds_f64 *dst = on ? stage_b + ((j & 7) * M + ic) : dump;
-                    *dst = dc[t];
-                }
+                for (int t = 0; t < 3; ++t) stage_b[(3 * l16 + t) * M + l16] = dc[t];
             }
-            {
-                const int row = NE + 3 * (l16 < NIF ? l16 : 0);
+            if (l16 < NIF) {         // face l16: rows NE + 3 l16 .. + 2 of the columns of its two cells
+                const int row = NE + 3 * l16;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const int ja = 3 * Ia + t, jb = 3 * Ib + t;
-                    const bool ona = (l16 < NIF) && ((ja >> 3) == q), onb = (l16 < NIF) && ((jb >> 3) == q);
-                    lds_f64 *ca_ = ona ? stage_b + ((ja & 7) * M + row) : dump3;
-                    lds_f64 *cb_ = onb ? stage_b + ((jb & 7) * M + row) : dump3;
+                    lds_f64 *ca_ = stage_b + ((3 * Ia + t) * M + row), *cb_ = stage_b + ((3 * Ib + t) * M + row);
                     ca_[0] = -Ba[0][t]; ca_[1] = -Ba[1][t]; ca_[2] = -Ba[2][t];
                     cb_[0] = Bb0[t]; cb_[1] = Ba[1][t]; cb_[2] = Ba[2][t];
                 }
             }
             lds_sync();
-            if (q == 0) NIN_STAMP();
-            const lds_f64 *mine = lds_base(stage + l8 * M + h);
+            NIN_STAMP();
 #pragma unroll
-            for (int rl = 0; rl < HR; ++rl) a[q][rl] = mine[2 * rl];
-            {   // the column's own cell-row entry d_i[t] (needed again for r_i = 1 - d_i . y_i): row i = j / 3
+            for (int q = 0; q < SLOTS; ++q) {
+                const lds_f64 *mine = lds_base(stage + (l8 + 8 * q) * M + h);
+#pragma unroll
+                for (int rl = 0; rl < HR; ++rl) a[q][rl] = mine[2 * rl];
+                // the column's own cell-row entry d_i[t] (needed again for r_i = 1 - d_i . y_i): row i = j / 3
                 const int j = l8 + 8 * q, i = (j * 43) >> 7;
-                dsave[q] = stage[l8 * M + i];
+                dsave[q] = stage[j * M + i];
+                y[q] = 0.0;
             }
-            y[q] = 0.0;
             lds_sync();
-            if (q == 0 || q == 1) NIN_STAMP();
+            NIN_STAMP();
         }
 #pragma unroll
         for (int e = 0; e < C::CS; ++e) cr[e] = (l16 + 16 * e < NE) ? 1.0 : 0.0;   // c = 1 on the cell rows
@@ -456,6 +447,14 @@ int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int 
     if (blocks > cap) blocks = cap;
     static const int max_blocks = getenv("NIN_GLS_MAX_BLOCKS") ? atoi(getenv("NIN_GLS_MAX_BLOCKS")) : 0;
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    static bool attr_set = false;
+    if (!attr_set) {   // 145 KB of dynamic LDS per block: above the default 64 KB limit
+        const void *ks[4] = {reinterpret_cast<const void *>(nin_gls_group_kernel<0>), reinterpret_cast<const void *>(nin_gls_group_kernel<1>),
+                             reinterpret_cast<const void *>(nin_gls_group_kernel<2>), reinterpret_cast<const void *>(nin_gls_group_kernel<3>)};
+        for (const void *k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return -3;
+        attr_set = true;
+    }
     static const int dbg = getenv("NIN_GLS_DEBUG_MODE") ? atoi(getenv("NIN_GLS_DEBUG_MODE")) : 0;
     if (dbg == 3) hipLaunchKernelGGL(nin_gls_group_kernel<3>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws);
     else if (dbg == 1) hipLaunchKernelGGL(nin_gls_group_kernel<1>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws);
