@@ -121,6 +121,54 @@ struct Hex8 {
     static constexpr int LANES = 16, NODES_PER_WAVE = 4;
 };
 
+// Everything a pass reads from HBM, fetched one pass ahead.  The reads form a dependent chain (node id ->
+// CSR row starts -> cell / face ids -> geometry -> permeability); issued back to back at the top of a pass
+// they cost ~12 k cycles of exposed latency (in-kernel stamps, tools/stamps_gls.py) of a ~57 k cycle pass, and
+// with one wave per SIMD nothing else hides it.  So each level is issued at a different point of the
+// PREVIOUS pass (top, after the faces, after the staging, Householder steps 6 and 12) and has long landed
+// when the next level needs it.
+struct NodeFetch {
+    int32_t p, eb, fb, cell, ca, cb;
+    size_t face;
+    bool valid;
+    double xv[3], cen[3], fcen[3], fn[3], da, db, Ka[9], Kb[9];
+
+    __device__ __forceinline__ void level0(const int32_t *nodes, int32_t idx, int32_t count) {
+        valid = idx < count;
+        const int32_t sel = valid ? idx : count - 1;
+        p = nodes ? nodes[sel] : sel;
+    }
+    __device__ __forceinline__ void level1(const GridView &g) {
+        eb = g.esup_ptr[p];
+        fb = g.fsup_ptr[p];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xv[k] = g.coords[3 * (size_t)p + k];
+    }
+    __device__ __forceinline__ void level2(const GridView &g, int l8, int sf) {
+        cell = g.esup[eb + l8];
+        face = (size_t)g.fsup[fb + sf];
+    }
+    __device__ __forceinline__ void level3(const GridView &g) {
+        ca = g.face_cells[2 * face];
+        cb = g.face_cells[2 * face + 1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cen[k] = g.centroids[3 * (size_t)cell + k];
+            fcen[k] = g.face_center[3 * face + k];
+            fn[k] = g.face_normal[3 * face + k];
+        }
+    }
+    __device__ __forceinline__ void level4(const GridView &g) {
+        da = g.diff_mag[ca];
+        db = g.diff_mag[cb];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            Ka[k] = g.perm[9 * (size_t)ca + k];
+            Kb[k] = g.perm[9 * (size_t)cb + k];
+        }
+    }
+};
+
 // One Householder step K (compile-time).  l8: column lane, h: row half, l16 = 8 h + l8.
 //
 // The published column lives in xb as two halves of HRP entries (row r -> half r % 2, slot r / 2).  The
@@ -131,8 +179,11 @@ struct Hex8 {
 // access is a laundered base + compile-time offset (see lds_base).
 template <int K>
 __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], double (&cr)[Hex8::CS], double (&rinv)[Hex8::SLOTS],
-                                        lds_f64 *xh, const lds_f64 *xc, lds_f64 *xalpha, int l8, int h, int l16) {
+                                        lds_f64 *xh, const lds_f64 *xc, lds_f64 *xalpha, int l8, int h, int l16,
+                                        NodeFetch &nx, const GridView &g) {
     using C = Hex8;
+    if (K == 6) nx.level3(g);    // next pass: geometry (its ids were fetched after this pass's staging)
+    if (K == 12) nx.level4(g);   // next pass: permeability and diff_mag of the faces' cells
     constexpr int QK = K / 8, LK = K % 8, HP = K % 2, PL = K / 2, RL0 = (K + 1) / 2, HR = C::HR;
     const bool owner = (l8 == LK);
     const bool pivot_half = (h == HP);
@@ -219,15 +270,15 @@ template <int K, int KEND>
 struct QrLoop {
     static __device__ __forceinline__ void run(double (&a)[Hex8::SLOTS][Hex8::HR], double (&cr)[Hex8::CS],
                                                double (&rinv)[Hex8::SLOTS], lds_f64 *xh, const lds_f64 *xc, lds_f64 *xalpha,
-                                               int l8, int h, int l16) {
-        qr_step<K>(a, cr, rinv, xh, xc, xalpha, l8, h, l16);
-        QrLoop<K + 1, KEND>::run(a, cr, rinv, xh, xc, xalpha, l8, h, l16);
+                                               int l8, int h, int l16, NodeFetch &nx, const GridView &g) {
+        qr_step<K>(a, cr, rinv, xh, xc, xalpha, l8, h, l16, nx, g);
+        QrLoop<K + 1, KEND>::run(a, cr, rinv, xh, xc, xalpha, l8, h, l16, nx, g);
     }
 };
 template <int KEND>
 struct QrLoop<KEND, KEND> {
     static __device__ __forceinline__ void run(double (&)[Hex8::SLOTS][Hex8::HR], double (&)[Hex8::CS], double (&)[Hex8::SLOTS],
-                                               lds_f64 *, const lds_f64 *, lds_f64 *, int, int, int) {}
+                                               lds_f64 *, const lds_f64 *, lds_f64 *, int, int, int, NodeFetch &, const GridView &) {}
 };
 
 // Back-substitution R y = b, row J (compile-time).  R(J, j) sits in lane (j % 8, J % 2) at local row J / 2,
@@ -286,48 +337,51 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
     unsigned long long stamps[8];
     int n_stamp = 0;
 #define NIN_STAMP() do { if (DBG == 3 && n_stamp < 8) { __builtin_amdgcn_sched_barrier(0); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
+    const int sf = l16 < NIF ? l16 : NIF - 1;   // lane's face (lanes 12..15 redo face 11 and write nothing)
+    NodeFetch cur, nx;
+    {
+        const int32_t wg0 = blockIdx.x * wpb + wave;
+        cur.level0(nodes, wg0 * GPW + grp, count);
+        cur.level1(g);
+        cur.level2(g, l8, sf);
+        cur.level3(g);
+        cur.level4(g);
+    }
     for (int32_t wg = blockIdx.x * wpb + wave; wg < n_groups; wg += gridDim.x * wpb) {
         if (DBG == 3) n_stamp = 0;
         NIN_STAMP();
-        const int32_t idx = wg * GPW + grp;
-        const bool valid = idx < count;
-        const int32_t sel = valid ? idx : count - 1;
-        const int32_t p = nodes ? nodes[sel] : sel;
-        const int32_t eb = g.esup_ptr[p], fb = g.fsup_ptr[p];
-        const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1],
-                     xv2 = g.coords[3 * (size_t)p + 2];
+        nx.level0(nodes, (wg + (int32_t)(gridDim.x * wpb)) * GPW + grp, count);   // a clamped (valid) node past the end
+        const bool valid = cur.valid;
+        const int32_t p = cur.p, eb = cur.eb;
+        const double xv0 = cur.xv[0], xv1 = cur.xv[1], xv2 = cur.xv[2];
         // lane l16 < 8 is cell l16 of the node: its row (x_K - x_v) (gls.pyx:269-277).  Lanes 8..15 redo
         // cell l16 - 8 (no zero-initialised merge values: those get hoisted out of the node loop as registers)
         double dc[3];
         {
-            const int32_t c = g.esup[eb + l8];
-            if (l16 < NE) cells[l16] = c;
-            dc[0] = g.centroids[3 * (size_t)c + 0] - xv0;
-            dc[1] = g.centroids[3 * (size_t)c + 1] - xv1;
-            dc[2] = g.centroids[3 * (size_t)c + 2] - xv2;
+            if (l16 < NE) cells[l16] = cur.cell;
+            dc[0] = cur.cen[0] - xv0;
+            dc[1] = cur.cen[1] - xv1;
+            dc[2] = cur.cen[2] - xv2;
         }
         lds_sync();
-        // lane l16 < 12 is face l16 of the node (lanes 12..15 redo face 11 and write nothing):
-        // B_a = [K_a N; T1; tau T2], B_b = [K_b N; T1; tau T2] (gls.pyx:293-321), kept in registers until
-        // the three slots have been staged.  B_b differs from B_a only in its first row.
+        // lane l16 < 12 is face l16 of the node: B_a = [K_a N; T1; tau T2], B_b = [K_b N; T1; tau T2]
+        // (gls.pyx:293-321), kept in registers until the system has been staged.  B_b differs from B_a only in
+        // its first row.
         double Ba[3][3], Bb0[3];   // Ba[e][t]
         int Ia = 0, Ib = 0;
         {
-            const int sf = l16 < NIF ? l16 : NIF - 1;
-            const size_t f = (size_t)g.fsup[fb + sf];
-            const int ca = g.face_cells[2 * f], cb = g.face_cells[2 * f + 1];
-            const double N0 = g.face_normal[3 * f + 0], N1 = g.face_normal[3 * f + 1], N2 = g.face_normal[3 * f + 2];
-            const double T0 = xv0 - g.face_center[3 * f + 0], T1 = xv1 - g.face_center[3 * f + 1],
-                         T2 = xv2 - g.face_center[3 * f + 2];
+            const int ca = cur.ca, cb = cur.cb;
+            const double N0 = cur.fn[0], N1 = cur.fn[1], N2 = cur.fn[2];
+            const double T0 = xv0 - cur.fcen[0], T1 = xv1 - cur.fcen[1], T2 = xv2 - cur.fcen[2];
             const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
-            const double da = g.diff_mag[ca], db = g.diff_mag[cb];
+            const double da = cur.da, db = cur.db;
             double eta = 0.0;
             eta = da > eta ? da : eta;
             eta = db > eta ? db : eta;
             // tau = |T_sj2|^(-eta) (gls.pyx:314): for a positive base pow(u, -eta) = exp(-eta log u)
             const double un = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
             const double tj = face_tau(un, eta);
-            const double *Ka = g.perm + 9 * (size_t)ca, *Kb = g.perm + 9 * (size_t)cb;
+            const double *Ka = cur.Ka, *Kb = cur.Kb;
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 const int cq = cells[q];
@@ -346,6 +400,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
         // ---- deal the matrix into registers, one slot (8 columns) at a time through the staging buffer.
         //      Column j = 3 i + t (cell i, component t) -> slot j / 8, column lane j % 8; this lane then keeps
         //      rows 2 rl + h of columns l8, l8 + 8, l8 + 16.  [-B_a | +B_b] per face, gls.pyx:340-356. -----------
+        nx.level1(g);   // next pass: CSR row starts + node coordinates
         double a[SLOTS][HR], cr[C::CS], dsave[SLOTS], y[SLOTS];
         lds_f64 *stage_l = lds_base(stage + l16);
         lds_f64 *stage_b = (lds_f64 *)stage;
@@ -382,6 +437,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
             lds_sync();
             NIN_STAMP();
         }
+        nx.level2(g, l8, sf);   // next pass: this lane's cell and face ids
 #pragma unroll
         for (int e = 0; e < C::CS; ++e) cr[e] = (l16 + 16 * e < NE) ? 1.0 : 0.0;   // c = 1 on the cell rows
 #pragma unroll
@@ -393,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
         for (int q = 0; q < SLOTS; ++q) rinv[q] = 0.0;
         NIN_STAMP();
         if (DBG != 1) QrLoop<0, NA>::run(a, cr, rinv, lds_base(xb + h * C::HRP), lds_base(xb + (l16 & 1) * C::HRP + (l16 >> 1)),
-                                         lds_base(xb + 2 * C::HRP), l8, h, l16);
+                                         lds_base(xb + 2 * C::HRP), l8, h, l16, nx, g);
         if (DBG != 1 && DBG != 2) BackLoop<NA - 1>::run(a, cr, rinv, y, l8, h, l16);
         NIN_STAMP();
         if (DBG == 1 || DBG == 2) { double acc = 0; for (int q = 0; q < SLOTS; ++q) for (int rl = 0; rl < HR; ++rl) acc += a[q][rl]; y[0] = acc; }
@@ -418,6 +474,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
         lds_sync();
         // gls.pyx:470-472 (only if an interior node carries the Neumann flag): neumann_ws = last cell's weight
         const bool is_neu = (g.flags[p] & 2) != 0;
+        if (DBG == 1) { nx.level3(g); nx.level4(g); }   // (diagnostic build without the QR: its prefetch hooks)
         if (h == 0) prod[l8] = w;
         lds_sync();
         const double nwv = is_neu ? prod[NE - 1] : 0.0;
@@ -431,6 +488,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
             const int32_t p0 = nodes ? nodes[0] : 0;   // debug build only: 4th pass of wave 0, into the row of its 1st node
             for (int i = 0; i < n_stamp; ++i) out[g.esup_ptr[p0] + i] = 1.0e6 + (double)(stamps[i] - stamps[0]);
         }
+        cur = nx;
     }
 }
 
