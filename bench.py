@@ -68,10 +68,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--method", default="gls", choices=["gls", "idw", "ls"])
-    ap.add_argument("--n", type=int, default=216, help="cells per edge per GPU (216^3 = 10,077,696)")
+    ap.add_argument("--edge", dest="n", type=int, default=216, help="cells per edge per GPU (216^3 = 10,077,696)")
     ap.add_argument("--jitter", type=float, default=0.15)
     ap.add_argument("--cpu-sample", type=int, default=64, help="edge of the CPU-baseline sample mesh (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the IDW/LS context numbers and the e2e timing")
+    ap.add_argument("--check", action="store_true",
+                    help="(small --edge only) rank 0 recomputes the whole mesh on its GPU and compares the gathered triplets")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,10 +89,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the weight kernels are HIP only (no CPU fallback)")
+    # Rehearsal on a one-GPU box: NIN_BENCH_REHEARSAL=1 puts every rank on device 0 and runs the exchange over gloo
+    # through host copies.  It exercises the slab / offset / padding logic only; it is never a measurement.
+    rehearsal = os.environ.get("NIN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def all_gather_into(out_t, in_t):
+        if rehearsal:
+            o = torch.empty(out_t.shape, dtype=out_t.dtype)
+            dist.all_gather_into_tensor(o, in_t.cpu())
+            out_t.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out_t, in_t)
 
     import ninpol_amd
     from ninpol_amd import mesh as M
@@ -121,7 +139,7 @@ def main():
     counts_own = torch.from_numpy(np.diff(esup_ptr[own_lo:own_hi + 1]).astype(np.int32)).to(dev)
     if world > 1:
         # static parts of the triplets, global ids; padded so that every rank sends the same length
-        lens = torch.tensor([ee - eb, n_owned], dtype=torch.int64, device=dev)
+        lens = torch.tensor([ee - eb, n_owned], dtype=torch.int64, device="cpu" if rehearsal else dev)
         all_lens = [torch.empty_like(lens) for _ in range(world)]
         dist.all_gather(all_lens, lens)
         all_lens = torch.stack(all_lens).cpu().numpy()
@@ -135,30 +153,55 @@ def main():
         g_cnt = torch.empty(world * mx_rows, dtype=torch.int32, device=dev)
     else:
         mx_nnz = ee - eb
-    out = torch.empty(max(plan.nnz, eb + mx_nnz), dtype=torch.float64, device=dev)
+    # two output buffers: the all-gather of step i runs (on RCCL's stream) under the kernel of step i + 1
+    n_buf = 2 if world > 1 else 1
+    outs = [torch.empty(max(plan.nnz, eb + mx_nnz), dtype=torch.float64, device=dev) for _ in range(n_buf)]
+    out = outs[0]
     nws = torch.empty(P_loc, dtype=torch.float64, device=dev)
+    pending = [None] * n_buf      # outstanding collectives reading outs[b]
+    step_no = [0]
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    def drain(b):
+        if pending[b] is not None:
+            for w in pending[b]:
+                w.wait()          # current stream waits for the collective; the host does not block
+            pending[b] = None
+
     def step(i=None):
+        b = step_no[0] % n_buf
+        step_no[0] += 1
+        drain(b)                  # the buffer (and the gather targets) of two steps ago must have been delivered
         if i is not None:
             ev[i][0].record(stream)
-        plan.launch(out.data_ptr(), nws.data_ptr(), stream.cuda_stream, add_neumann=True)
+        plan.launch(outs[b].data_ptr(), nws.data_ptr(), stream.cuda_stream, add_neumann=True)
         if i is not None:
             ev[i][1].record(stream)
         if world > 1:   # the single exchange step of the path: (count, column, value) of every owned row
-            dist.all_gather_into_tensor(g_vals, out[eb:eb + mx_nnz])
-            dist.all_gather_into_tensor(g_cols, cols_pad)
-            dist.all_gather_into_tensor(g_cnt, cnt_pad)
+            if rehearsal:
+                all_gather_into(g_vals, outs[b][eb:eb + mx_nnz])
+                all_gather_into(g_cols, cols_pad)
+                all_gather_into(g_cnt, cnt_pad)
+            else:
+                pending[b] = [dist.all_gather_into_tensor(g_vals, outs[b][eb:eb + mx_nnz], async_op=True),
+                              dist.all_gather_into_tensor(g_cols, cols_pad, async_op=True),
+                              dist.all_gather_into_tensor(g_cnt, cnt_pad, async_op=True)]
+
+    def drain_all():
+        for b in range(n_buf):
+            drain(b)
 
     for _ in range(args.warmup):
         step()
+    drain_all()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain_all()                   # every step's triplets have been delivered on every rank
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -166,14 +209,37 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     if world > 1:
-        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+        rdev = "cpu" if rehearsal else dev
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
-        tot = torch.tensor([n_owned], dtype=torch.int64, device=dev)
+        tot = torch.tensor([n_owned], dtype=torch.int64, device=rdev)
         dist.all_reduce(tot)
         total_nodes = int(tot[0])
     else:
         total_nodes = n_owned
+
+    check = None
+    if args.check and world > 1 and rank == 0:
+        # reassemble what the all-gather delivered and compare with the whole mesh computed on this GPU
+        whole = M.hex_mesh(n, n, nz_global, lengths=(1.0, 1.0, float(world)), jitter=args.jitter, seed=0)
+        M.attach_fields(whole, "u", perm="ALH")
+        Iw = ninpol_amd.Interpolator(device=local_rank)
+        Iw.load_mesh(mesh_obj=whole)
+        pw = Iw.device_plan("u", args.method)
+        ow = torch.empty(pw.nnz, dtype=torch.float64, device=dev)
+        nw = torch.empty(pw.n_points, dtype=torch.float64, device=dev)
+        pw.launch(ow.data_ptr(), nw.data_ptr(), stream.cuda_stream, add_neumann=True)
+        torch.cuda.synchronize()
+        vals, cols, cnts = [], [], []
+        for r in range(world):
+            vals.append(g_vals[r * mx_nnz:r * mx_nnz + int(all_lens[r, 0])])
+            cols.append(g_cols[r * mx_nnz:r * mx_nnz + int(all_lens[r, 0])])
+            cnts.append(g_cnt[r * mx_rows:r * mx_rows + int(all_lens[r, 1])])
+        vals, cols, cnts = torch.cat(vals).cpu().numpy(), torch.cat(cols).cpu().numpy(), torch.cat(cnts).cpu().numpy()
+        gw = Iw.grid
+        check = bool(np.array_equal(cnts, np.diff(gw.esup_ptr)) and np.array_equal(cols, gw.esup)
+                     and np.array_equal(vals, ow.cpu().numpy()))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -196,7 +262,8 @@ def main():
             "config": {"workload": f"{args.method.upper()} interpolate() weights, {n}x{n}x{n * world} hexahedra "
                                    f"({n ** 3 * world} cells, {total_nodes} nodes), jitter {args.jitter}, ALH permeability, "
                                    "all-Dirichlet boundary; inputs resident in HBM, output CSR values on device"
-                                   + ("; + RCCL all-gather of (count, column, value) per step" if world > 1 else ""),
+                                   + ("; + RCCL all-gather of (count, column, value) per step, overlapped with the next "
+                                      "step's kernel (two output buffers)" if world > 1 else ""),
                        "cells_per_gpu": n ** 3, "nodes_total": total_nodes, "nnz_esup_rank0": plan.nnz,
                        "parallelism": f"node-block shards x{world}, neighbour cells replicated" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -205,6 +272,10 @@ def main():
                          "algorithmic_bytes_per_launch": B_alg, "bytes_per_node": round(B_alg / P_loc, 1)},
             "setup_s": {"mesh_gen": round(t_gen, 2), "load_mesh": round(t_load, 2), "push_to_hbm": round(t_push, 2)},
         }
+        if check is not None:
+            line["gather_check_bit_identical_to_single_gpu"] = check
+        if rehearsal:
+            line["data"] = "synthetic (REHEARSAL: all ranks on one GPU, gloo through host copies -- not a measurement)"
         if args.method == "gls":
             flops = REF_FLOPS_PER_NODE_HEX * P_loc / (kern_ms * 1e-3) / 1e12
             line["fp64"] = {"ref_equiv_tflops": round(flops, 3), "peak_tflops": FP64_PEAK_TFLOPS,
@@ -228,7 +299,7 @@ def main():
                 line[meth] = {"kernel_ms": round(ms, 4), "Mnodes_per_s": round(P_loc / ms / 1e3, 1),
                               "achieved_GBps": round(p2.algorithmic_bytes / (ms * 1e-3) / 1e9, 1),
                               "frac_hbm": round(p2.algorithmic_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            del out, nws
+            del out, outs, nws
             torch.cuda.empty_cache()
             t0 = time.time()
             W, _ = I.interpolate("u", args.method)

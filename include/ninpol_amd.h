@@ -120,6 +120,12 @@ int nin_weights_host(nin_grid *g, int method, const int64_t *targets, int64_t n_
 int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indptr, int32_t *indices,
                          double *data, int64_t *nnz_out, void *stream);
 
+/* interpolate() in one call, host outputs: weights (with `+ neumann_ws[row]`, interpolator.pyx:618) for ALL nodes,
+ * then the device-side csr_matrix + eliminate_zeros of interpolator.pyx:622-624.  indptr [n_points+1], indices and
+ * data sized by the caller to nnz_esup (upper bound), neumann_ws [n_points]; *nnz_out = surviving entries. */
+int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *indices, double *data,
+                             int64_t *nnz_out, double *neumann_ws);
+
 /* Algorithmic HBM bytes one nin_weights call moves for `method` over all nodes (DESIGN.md formula,
  * SURVEY 8d): used by bench.py for the roofline line. */
 int64_t nin_algorithmic_bytes(const nin_grid *g, int method);

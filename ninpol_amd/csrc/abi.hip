@@ -484,6 +484,28 @@ int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indpt
     return NIN_OK;
 }
 
+int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *indices, double *data,
+                             int64_t *nnz_out, double *neumann_ws) {
+    if (!g || !indptr || !indices || !data || !nnz_out || !neumann_ws) return fail(NIN_EINVAL, "NULL argument");
+    DeviceGrid &d = g->d;
+    if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
+    HIP_TRY(hipSetDevice(d.device));
+    const size_t nb = (size_t)std::max<int64_t>(d.nnz_e, 1) * 8, pb = (size_t)g->h.n_points * 8;
+    double *dd = nullptr, *dn = nullptr;
+    HIP_TRY(hipMalloc((void **)&dd, nb));
+    hipError_t e = hipMalloc((void **)&dn, pb);
+    if (e != hipSuccess) { (void)hipFree(dd); return fail(NIN_ENOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    int rc = nin_weights_device(g, method, nullptr, 0, 1, dd, dn, nullptr);
+    if (!rc) rc = nin_csr_compact_host(g, dd, indptr, indices, data, nnz_out, nullptr);
+    if (!rc) {
+        e = hipMemcpy(neumann_ws, dn, pb, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(NIN_EHIP, "copy back: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dd);
+    (void)hipFree(dn);
+    return rc;
+}
+
 int64_t nin_algorithmic_bytes(const nin_grid *g, int method) {
     if (!g) return -1;
     // SURVEY 8(d), canonical device layout s_i = 4:

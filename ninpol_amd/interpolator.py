@@ -59,9 +59,9 @@ class _MethodPlugin:
     __call__ = prepare
 
 
-def _run_weights(grid, method, cells_data, points_data, variable_to_index, variable, target_points, add_neumann):
+def _upload_fields(grid, method, cells_data, points_data, variable_to_index, variable):
     """Look the field rows up exactly as the plugins do (idw.pyx:27, ls.pyx:27, gls.pyx:47-59; a missing
-    name is a KeyError there too), hand them to the device and run the kernel."""
+    name is a KeyError there too) and hand them to the device."""
     L = _lib.load()
     if grid.device < 0:
         grid.to_device(0)
@@ -75,6 +75,13 @@ def _run_weights(grid, method, cells_data, points_data, variable_to_index, varia
         dmag = np.ascontiguousarray(cd[v2i["cells"]["diff_mag"]][:E], dtype=DTYPE_F)
         nval = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_" + variable]][:P], dtype=DTYPE_F)
     _lib.check(L.nin_fields_set(grid._h, _ptr(perm), _ptr(dmag), _ptr(flag), _ptr(nval)))
+
+
+def _run_weights(grid, method, cells_data, points_data, variable_to_index, variable, target_points, add_neumann):
+    """Upload the fields and run the kernel; weights come back in CSR position (esup layout)."""
+    L = _lib.load()
+    _upload_fields(grid, method, cells_data, points_data, variable_to_index, variable)
+    P = grid.n_points
     targets = np.ascontiguousarray(target_points, dtype=DTYPE_I)
     full = len(targets) == 0 or (len(targets) == P and np.array_equal(targets, np.arange(P)))
     csr = np.empty(len(grid.esup), dtype=DTYPE_F)
@@ -276,13 +283,26 @@ class Interpolator:
         if g.device < 0:
             g.to_device(self.device)
         t0 = time.time()
-        # `data[j] = weights[i, j - esup_ptr[point]] + neumann_ws[i]` (interpolator.pyx:618) is fused
-        # into the kernel (add_neumann); the result arrives already in CSR position.
+        full = len(target_points) == P and np.array_equal(target_points, np.arange(P))
+        idx_t = np.int32 if max(len(g.esup), E, P) < np.iinfo(np.int32).max else np.int64
+        if full and idx_t is np.int32:
+            # one native call: kernel with `data[j] = weights + neumann_ws[row]` (interpolator.pyx:618) fused, then the
+            # device-side csr_matrix + eliminate_zeros (interpolator.pyx:622-624); only the surviving entries cross PCIe
+            _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable)
+            nnz_max = len(g.esup)
+            indptr = np.empty(P + 1, dtype=np.int32)
+            indices = np.empty(nnz_max, dtype=np.int32)
+            data = np.empty(nnz_max, dtype=DTYPE_F)
+            nws = np.empty(P, dtype=DTYPE_F)
+            nnz = ctypes.c_int64(0)
+            _lib.check(_lib.load().nin_interpolate_csr_host(g._h, _lib.METHOD_ID[method], _ptr(indptr), _ptr(indices),
+                                                            _ptr(data), ctypes.byref(nnz), _ptr(nws)))
+            self._log(f"Interpolation done in {time.time() - t0:.2f} seconds")
+            W = sp.csr_matrix((data[:nnz.value], indices[:nnz.value], indptr), shape=(P, E))
+            return W, nws
         csr, nws = _run_weights(g, method, self.cells_data, self.points_data, self.variable_to_index, variable,
                                 target_points, add_neumann=True)
         self._log(f"Interpolation done in {time.time() - t0:.2f} seconds")
-        full = len(target_points) == P and np.array_equal(target_points, np.arange(P))
-        idx_t = np.int32 if max(len(g.esup), E, P) < np.iinfo(np.int32).max else np.int64
         if full:
             W = sp.csr_matrix((csr, g.esup.astype(idx_t), g.esup_ptr.astype(idx_t)), shape=(P, E))
         else:
