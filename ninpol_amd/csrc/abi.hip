@@ -287,6 +287,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
     std::vector<std::vector<int32_t>> lists(kGlsClasses);
     std::vector<int32_t> hex8_list;
     const bool use_group = getenv("NIN_GLS_NO_GROUP") == nullptr;   // debugging switch: force the generic kernel
+    const bool force_global = getenv("NIN_GLS_FORCE_GLOBAL") != nullptr;   // testing switch: systems in global scratch
     int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0};
     for (int64_t p = 0; p < P; ++p) {
         const int64_t ne = h.esup_ptr[p + 1] - h.esup_ptr[p], nf = h.fsup_ptr[p + 1] - h.fsup_ptr[p];
@@ -301,7 +302,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         const int64_t doubles = ((ne + 1) >> 1) + n + m * n;
         const int64_t bytes = ((doubles * 8 + 15) / 16) * 16;
         int c = kGlsClasses - 1;
-        for (int k = 0; k < kGlsClasses - 1; ++k)
+        for (int k = 0; k < kGlsClasses - 1 && !force_global; ++k)
             if (bytes <= kClassBudget[k]) { c = k; break; }
         g->node_class[p] = (uint8_t)c;
         lists[c].push_back((int32_t)p);

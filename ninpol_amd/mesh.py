@@ -183,6 +183,23 @@ def mixed_mesh(nx, ny=None, nz=None, n_hex=None, lengths=(1.0, 1.0, 1.0), jitter
                       CellBlock("tetra", tets)])
 
 
+def quad_tri_mesh_2d(nx, ny=None, jitter=0.0, seed=0):
+    """2-D mesh on the unit square: left half quads, right half triangles (each lattice cell cut along its
+    0-2 diagonal).  Points are (P, 3) with z = 0, as meshio delivers 2-D meshes."""
+    ny = nx if ny is None else ny
+    pts = _lattice_points(nx, ny, 1, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), jitter, seed, 0, 0)
+    pts[:, 2] = 0.0
+    sx = nx + 1
+    j, i = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    n0 = (i + j * sx).ravel().astype(np.int64)
+    q = np.stack([n0, n0 + 1, n0 + 1 + sx, n0 + sx], axis=1)
+    left = (i.ravel() < nx // 2)
+    quads = q[left]
+    qt = q[~left]
+    tris = np.stack([qt[:, [0, 1, 2]], qt[:, [0, 2, 3]]], axis=1).reshape(-1, 3)
+    return Mesh(pts, [CellBlock("quad", quads), CellBlock("triangle", tris)])
+
+
 def _fix_tet_orientation(pts, tets):
     a, b, c, d = (pts[tets[:, i]] for i in range(4))
     vol = np.einsum("ij,ij->i", np.cross(b - a, c - a), d - a)

@@ -82,3 +82,49 @@ def test_gpu_target_subset(oracle_lib):
         assert util.rowscaled_err(nw, no[targets]) <= util.WEIGHT_RTOL
         W, nws = I.interpolate("u", meth, targets)
         assert W.shape == (len(targets), I.grid.n_elems)
+
+
+def test_gpu_2d_idw_ls(oracle_lib):
+    """2-D quad + triangle mesh (z = 0): IDW uses grid.dim coordinates (idw.pyx:66), LS always three."""
+    mesh = M.quad_tri_mesh_2d(12, 9, jitter=0.1, seed=1)
+    M.attach_fields(mesh, "u", perm="LIN")
+    o = oracle_lib.OracleInterpolator("port", threads=2)
+    o.load_mesh(mesh)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    for meth in ("idw", "ls"):
+        wo, _ = o.prepare(meth, "u")
+        w, _ = I.prepare_interpolator(meth, "u", np.arange(I.grid.n_points))
+        assert util.rowscaled_err(w, wo) <= TIGHT, meth
+
+
+def test_gpu_gls_global_scratch_path(oracle_lib, monkeypatch):
+    """Systems too large for LDS run the general kernel on a global-memory slot per wave; forced here
+    (NIN_GLS_FORCE_GLOBAL) on a small mixed mesh so that the path is exercised."""
+    monkeypatch.setenv("NIN_GLS_FORCE_GLOBAL", "1")
+    monkeypatch.setenv("NIN_GLS_NO_GROUP", "1")
+    mesh = M.mixed_mesh(6, 4, 4, jitter=0.1, seed=8)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=2)
+    o = oracle_lib.OracleInterpolator("port", threads=2)
+    o.load_mesh(mesh)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    wo, no = o.prepare("gls", "u")
+    w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+    assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL
+    assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
+
+
+def test_gpu_generic_kernel_on_hex(oracle_lib, monkeypatch):
+    """The general one-node-per-wavefront kernel on hexahedron interior nodes (group kernel switched off)."""
+    monkeypatch.setenv("NIN_GLS_NO_GROUP", "1")
+    mesh = M.hex_mesh(9, jitter=0.15, seed=5)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(0, 1.0), seed=2)
+    o = oracle_lib.OracleInterpolator("port", threads=2)
+    o.load_mesh(mesh)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    wo, no = o.prepare("gls", "u")
+    w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+    assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL
+    assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL

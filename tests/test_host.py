@@ -155,3 +155,22 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"ninpol_oracle|oracle/|libninpol_oracle|ninpol_ref_driver", text):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_2d_mesh_host_grid_matches_oracle(lib, oracle_lib):
+    """dim = 2: faces are the elements' edges (interpolator.pyx:296-298); grid arrays against the oracle
+    (and against the reference build when present)."""
+    import ninpol_amd
+    mesh = M.quad_tri_mesh_2d(8, 6, jitter=0.1, seed=3)
+    M.attach_fields(mesh, "u", perm="LIN")
+    backends = ["port"] + (["reference"] if oracle_lib.have_reference() else [])
+    I = ninpol_amd.Interpolator()
+    I.load_mesh(mesh_obj=mesh)
+    assert I.grid.dim == 2
+    for be in backends:
+        o = oracle_lib.OracleInterpolator(be, threads=1)
+        o.load_mesh(mesh)
+        for k in util.GRID_SCALARS:
+            assert getattr(I.grid, k) == getattr(o.grid, k), (be, k)
+        for k in util.GRID_ARRAYS:
+            np.testing.assert_array_equal(getattr(I.grid, k), getattr(o.grid, k), err_msg=f"{be}:{k}")

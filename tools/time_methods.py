@@ -1,0 +1,22 @@
+"""Time the three methods on a few mesh families (kernel-only, through DevicePlan)."""
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import ninpol_amd
+from ninpol_amd import mesh as M
+cases = {"tet40": lambda: M.tet_mesh(40, jitter=0.1), "wedge60": lambda: M.wedge_mesh(60, jitter=0.05),
+         "mixed": lambda: M.mixed_mesh(100, 60, 60, jitter=0.1), "hex100": lambda: M.hex_mesh(100, jitter=0.15)}
+for name in (sys.argv[1:] or cases):
+    m = cases[name](); M.attach_fields(m, "u", perm="ALH")
+    I = ninpol_amd.Interpolator(); I.load_mesh(mesh_obj=m)
+    st = torch.cuda.current_stream()
+    for meth in ("idw", "ls", "gls"):
+        plan = I.device_plan("u", meth)
+        out = torch.empty(plan.nnz, dtype=torch.float64, device="cuda"); nws = torch.empty(plan.n_points, dtype=torch.float64, device="cuda")
+        plan.launch(out.data_ptr(), nws.data_ptr(), st.cuda_stream); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        for _ in range(3): plan.launch(out.data_ptr(), nws.data_ptr(), st.cuda_stream)
+        b.record(st); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 3
+        print(f"{name}: E={I.grid.n_elems} P={I.grid.n_points} MX={I.grid.MX_ELEMENTS_PER_POINT}/{I.grid.MX_FACES_PER_POINT} {meth}: {ms:.3f} ms = {I.grid.n_points/ms/1e3:.2f} Mnodes/s")
