@@ -123,7 +123,10 @@ def main():
     M.attach_fields(mesh, "u", perm="ALH")
     t_gen = time.time() - t0
     t0 = time.time()
-    I = ninpol_amd.Interpolator(device=local_rank)
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers; the host grid build is OpenMP code, so give
+    # every rank its share of the host cores explicitly (setup only, outside the timed region)
+    host_threads = max(1, (os.cpu_count() or 1) // world) if world > 1 else 0
+    I = ninpol_amd.Interpolator(device=local_rank, num_threads=host_threads)
     I.load_mesh(mesh_obj=mesh)
     t_load = time.time() - t0
     del mesh
