@@ -41,18 +41,36 @@ __device__ __forceinline__ void idw_row(const GridView &g, int32_t p, const int3
     const double x0 = g.coords[3 * (size_t)p + 0], x1 = g.coords[3 * (size_t)p + 1], x2 = g.coords[3 * (size_t)p + 2];
     double total = 0.0;
     int n_source = 0, zero_at = -1;
-    for (int j = 0; j < n; ++j) {
-        const size_t s = (size_t)cells[j];
-        double d0 = x0 - g.centroids[3 * s + 0];
-        double dist = 0.0 + d0 * d0;
-        if (g.dim > 1) { double d1 = x1 - g.centroids[3 * s + 1]; dist = dist + d1 * d1; }
-        if (g.dim > 2) { double d2 = x2 - g.centroids[3 * s + 2]; dist = dist + d2 * d2; }
-        if (dist <= (double)machine_epsilon) { zero_at = j; break; }
-        dist = sqrt(dist);
-        const double inv = 1 / dist;
-        w[j] = inv;
-        total += inv;
-        n_source += 1;
+    // the centroids of 8 neighbours are requested before any of them is used (one round trip per chunk
+    // instead of one per neighbour); the arithmetic below is still the reference's sequential loop
+    for (int j0 = 0; j0 < n && zero_at < 0; j0 += 8) {
+        double c[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t s = (size_t)cells[j0 + u < n ? j0 + u : n - 1];
+            c[u][0] = g.centroids[3 * s + 0];
+            c[u][1] = g.centroids[3 * s + 1];
+            c[u][2] = g.centroids[3 * s + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u;
+            if (j < n && zero_at < 0) {
+                double d0 = x0 - c[u][0];
+                double dist = 0.0 + d0 * d0;
+                if (g.dim > 1) { double d1 = x1 - c[u][1]; dist = dist + d1 * d1; }
+                if (g.dim > 2) { double d2 = x2 - c[u][2]; dist = dist + d2 * d2; }
+                if (dist <= (double)machine_epsilon) {
+                    zero_at = j;
+                } else {
+                    dist = sqrt(dist);
+                    const double inv = 1 / dist;
+                    w[j] = inv;
+                    total += inv;
+                    n_source += 1;
+                }
+            }
+        }
     }
     if (zero_at >= 0) {  // node sits on a centroid: row = e_j (idw.pyx:69-74)
         for (int j = 0; j < n; ++j) w[j] = (j == zero_at) ? 1.0 : 0.0;
@@ -65,12 +83,26 @@ __device__ __forceinline__ void idw_row(const GridView &g, int32_t p, const int3
 __device__ __forceinline__ void ls_row(const GridView &g, int32_t p, const int32_t *cells, double *w, int n) {
     const double x0 = g.coords[3 * (size_t)p + 0], x1 = g.coords[3 * (size_t)p + 1], x2 = g.coords[3 * (size_t)p + 2];
     double Ix = 0, Iy = 0, Iz = 0, Ixx = 0, Ixy = 0, Ixz = 0, Iyy = 0, Iyz = 0, Izz = 0;
-    for (int j = 0; j < n; ++j) {
-        const size_t s = (size_t)cells[j];
-        const double vx = g.centroids[3 * s + 0] - x0, vy = g.centroids[3 * s + 1] - x1, vz = g.centroids[3 * s + 2] - x2;
-        Ix = Ix + vx; Iy = Iy + vy; Iz = Iz + vz;
-        Ixx = Ixx + vx * vx; Ixy = Ixy + vx * vy; Ixz = Ixz + vx * vz;
-        Iyy = Iyy + vy * vy; Iyz = Iyz + vy * vz; Izz = Izz + vz * vz;
+    double v8[8][3];   // (x_K - x_v) of the first 8 neighbours, reused by the weight loop below
+    for (int j0 = 0; j0 < n; j0 += 8) {
+        double c[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {   // 8 centroid gathers in flight, then the reference's sequential sums
+            const size_t s = (size_t)cells[j0 + u < n ? j0 + u : n - 1];
+            c[u][0] = g.centroids[3 * s + 0];
+            c[u][1] = g.centroids[3 * s + 1];
+            c[u][2] = g.centroids[3 * s + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (j0 + u < n) {
+                const double vx = c[u][0] - x0, vy = c[u][1] - x1, vz = c[u][2] - x2;
+                if (j0 == 0) { v8[u][0] = vx; v8[u][1] = vy; v8[u][2] = vz; }
+                Ix = Ix + vx; Iy = Iy + vy; Iz = Iz + vz;
+                Ixx = Ixx + vx * vx; Ixy = Ixy + vx * vy; Ixz = Ixz + vx * vz;
+                Iyy = Iyy + vy * vy; Iyz = Iyz + vy * vz; Izz = Izz + vz * vz;
+            }
+        }
     }
     const bool planar = (Iz == 0.0 && Izz == 0.0 && Ixz == 0.0 && Iyz == 0.0);
     if (planar) Izz = 1.0;
@@ -92,7 +124,14 @@ __device__ __forceinline__ void ls_row(const GridView &g, int32_t p, const int32
     const double ly = (Ix * (Ixy * Izz - Iyz * Ixz) + Iy * (Ixz * Ixz - Ixx * Izz) + Iz * (Ixx * Iyz - Ixy * Ixz)) / D;
     const double lz = (Ix * (Iyy * Ixz - Ixy * Iyz) + Iy * (Ixx * Iyz - Ixy * Ixz) + Iz * (Ixy * Ixy - Ixx * Iyy)) / D;
     const double denom = (double)n + lx * Ix + ly * Iy + lz * Iz;
-    for (int j = 0; j < n; ++j) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u < n) {
+            double wi = (1. + lx * v8[u][0] + ly * v8[u][1] + lz * v8[u][2]);
+            w[u] = wi / denom;
+        }
+    }
+    for (int j = 8; j < n; ++j) {
         const size_t s = (size_t)cells[j];
         const double vx = g.centroids[3 * s + 0] - x0, vy = g.centroids[3 * s + 1] - x1, vz = g.centroids[3 * s + 2] - x2;
         double wi = (1. + lx * vx + ly * vy + lz * vz);
