@@ -126,6 +126,12 @@ int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indpt
 int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *indices, double *data,
                              int64_t *nnz_out, double *neumann_ws);
 
+/* Interpolate a cell field to the nodes without materialising the matrix on the host: weights for all nodes (with the
+ * `+ neumann_ws[row]` of interpolator.pyx:618), then node_values = W . u_cells on the device -- what the reference's
+ * callers compute next as `weights.dot(u)` (tests/utils/analytical.py:236).  Host pointers: u_cells [n_elems],
+ * node_values [n_points] (0 on the empty rows of Dirichlet nodes), neumann_ws [n_points]. */
+int nin_apply_host(nin_grid *g, int method, const double *u_cells, double *node_values, double *neumann_ws);
+
 /* Algorithmic HBM bytes one nin_weights call moves for `method` over all nodes (DESIGN.md formula,
  * SURVEY 8d): used by bench.py for the roofline line. */
 int64_t nin_algorithmic_bytes(const nin_grid *g, int method);

@@ -507,6 +507,30 @@ int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *
     return rc;
 }
 
+int nin_apply_host(nin_grid *g, int method, const double *u_cells, double *node_values, double *neumann_ws) {
+    if (!g || !u_cells || !node_values || !neumann_ws) return fail(NIN_EINVAL, "NULL argument");
+    DeviceGrid &d = g->d;
+    if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
+    HIP_TRY(hipSetDevice(d.device));
+    const size_t nb = (size_t)std::max<int64_t>(d.nnz_e, 1) * 8, pb = (size_t)g->h.n_points * 8, eb = (size_t)g->h.n_elems * 8;
+    double *dd = nullptr, *dn = nullptr, *du = nullptr, *dv = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dd); (void)hipFree(dn); (void)hipFree(du); (void)hipFree(dv); };
+#define TRY_A(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    TRY_A(hipMalloc((void **)&dd, nb));
+    TRY_A(hipMalloc((void **)&dn, pb));
+    TRY_A(hipMalloc((void **)&du, eb));
+    TRY_A(hipMalloc((void **)&dv, pb));
+    TRY_A(hipMemcpy(du, u_cells, eb, hipMemcpyHostToDevice));
+    int rc = nin_weights_device(g, method, nullptr, 0, 1, dd, dn, nullptr);
+    if (!rc) rc = launch_apply(d.v, dd, du, dv, nullptr);
+    if (rc) { cleanup(); return rc < 0 && g_err.empty() ? fail(rc, "launch failed") : rc; }
+    TRY_A(hipMemcpy(node_values, dv, pb, hipMemcpyDeviceToHost));
+    TRY_A(hipMemcpy(neumann_ws, dn, pb, hipMemcpyDeviceToHost));
+#undef TRY_A
+    cleanup();
+    return NIN_OK;
+}
+
 int64_t nin_algorithmic_bytes(const nin_grid *g, int method) {
     if (!g) return -1;
     // SURVEY 8(d), canonical device layout s_i = 4:

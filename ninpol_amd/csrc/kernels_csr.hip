@@ -40,6 +40,18 @@ __global__ __launch_bounds__(256) void nin_compact_kernel(GridView g, const doub
     }
 }
 
+// values[p] = sum_j data[esup_ptr[p] + j] * u[esup[esup_ptr[p] + j]]: what every caller of interpolate() does next
+// (`weights.dot(u)`, tests/utils/analytical.py:236), without the matrix leaving the device.  One lane per node;
+// rows are contiguous so a wavefront streams a contiguous run of data / esup; u is gathered (L2).
+__global__ __launch_bounds__(256) void nin_apply_kernel(GridView g, const double *__restrict__ data,
+                                                        const double *__restrict__ u, double *__restrict__ values) {
+    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < g.n_points; p += gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int32_t q = g.esup_ptr[p]; q < g.esup_ptr[p + 1]; ++q) acc += data[q] * u[g.esup[q]];
+        values[p] = acc;
+    }
+}
+
 int grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -55,6 +67,11 @@ int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipS
 int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr, int32_t *indices,
                    double *vals, hipStream_t stream) {
     hipLaunchKernelGGL(nin_compact_kernel, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, new_ptr, indices, vals);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_apply(const GridView &g, const double *data, const double *u, double *values, hipStream_t stream) {
+    hipLaunchKernelGGL(nin_apply_kernel, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, u, values);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

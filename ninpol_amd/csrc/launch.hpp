@@ -29,6 +29,8 @@ int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipS
 int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr, int32_t *indices,
                    double *vals, hipStream_t stream);
 
+int launch_apply(const GridView &g, const double *data, const double *u, double *values, hipStream_t stream);
+
 const char *kernel_name_idw();
 const char *kernel_name_ls();
 const char *kernel_name_gls();

@@ -317,6 +317,32 @@ class Interpolator:
         W.eliminate_zeros()
         return W, nws
 
+    def apply(self, variable, method, values=None):
+        """Interpolate a cell field to the nodes on the device: `W.dot(u)` of the reference's callers
+        (tests/utils/analytical.py:236) without bringing W to the host.  `values`: cell array (default: the
+        cell variable `variable` itself).  Returns (node_values, neumann_ws); Dirichlet rows are 0."""
+        if not self.is_grid_initialized:
+            raise ValueError("Grid not initialized. Please load a mesh first.")
+        if method not in self.supported_methods:
+            raise ValueError(f"Method '{method}' not supported. Supported methods are: "
+                             f"{list(self.supported_methods.keys())}")
+        if variable not in self.variable_to_index["cells"]:
+            raise ValueError(f"Variable '{variable}' not found in cells data. "
+                             "Point -> Cell interpolation not supported yet.")
+        g = self.grid
+        if g.device < 0:
+            g.to_device(self.device)
+        if values is None:
+            values = np.asarray(self.cells_data[self.variable_to_index["cells"][variable]])[:g.n_elems]
+        u = np.ascontiguousarray(values, dtype=DTYPE_F)
+        if u.shape != (g.n_elems,):
+            raise ValueError(f"values must have shape ({g.n_elems},), not {u.shape}.")
+        _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable)
+        out = np.empty(g.n_points, dtype=DTYPE_F)
+        nws = np.empty(g.n_points, dtype=DTYPE_F)
+        _lib.check(_lib.load().nin_apply_host(g._h, _lib.METHOD_ID[method], _ptr(u), _ptr(out), _ptr(nws)))
+        return out, nws
+
     def device_plan(self, variable, method):
         """Upload the fields of (variable, method) and return a DevicePlan (kernel-only launches)."""
         return DevicePlan(self, variable, method)

@@ -128,3 +128,18 @@ def test_gpu_generic_kernel_on_hex(oracle_lib, monkeypatch):
     w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
     assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL
     assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
+
+
+def test_gpu_apply_matches_matrix_product():
+    """Interpolator.apply == interpolate().dot(u) (the reference callers' next step, analytical.py:236)."""
+    mesh = M.mixed_mesh(10, 6, 6, jitter=0.1, seed=2)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=4)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    u = np.concatenate(mesh.cell_data["u"])
+    for meth in ("idw", "ls", "gls"):
+        W, nws = I.interpolate("u", meth)
+        vals, nws2 = I.apply("u", meth)
+        ref = W.dot(u)
+        np.testing.assert_array_equal(nws, nws2)
+        assert np.abs(vals - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), meth
