@@ -22,6 +22,7 @@ UNITS = [
     # IDW / LS: contraction off so results are the reference's bit for bit
     ("kernels_idw_ls.hip", "hipcc", ["-ffp-contract=off"]),
     ("kernels_gls.hip", "hipcc", []),
+    ("kernels_gls_block.hip", "hipcc", []),
     ("kernels_gls_group.hip", "hipcc", []),
     ("kernels_csr.hip", "hipcc", []),
     ("abi.hip", "hipcc", ["-Wno-unknown-pragmas"]),
@@ -55,7 +56,7 @@ def build(force=False, verbose_resources=False):
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         common = ["-O3", "-fPIC", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", obj]
         if cc == "hipcc":
-            cmd = [_hipcc(), f"--offload-arch={ARCH}"] + extra + common
+            cmd = [_hipcc(), f"--offload-arch={ARCH}"] + extra + os.environ.get("NIN_EXTRA_HIPCC_FLAGS", "").split() + common
             if verbose_resources:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         else:

@@ -72,8 +72,10 @@ void dev_free_all(DeviceGrid &d) {
     d = DeviceGrid{};
 }
 
-// LDS bytes per wave a node's system may take in class c (last class = global-memory scratch)
-const int32_t kClassBudget[kGlsClasses] = {9216, 16384, 32768, 65536, 159744, 0};
+// LDS bytes a node's system may take in class c and the waves per node the block kernel runs it with
+// (16 / 5 / 2 / 1 workgroups per CU); the last class keeps its systems in global-memory scratch.
+const int32_t kClassBudget[kGlsClasses] = {10240, 32768, 81920, 159744, 0};
+const int32_t kClassWaves[kGlsClasses] = {1, 2, 4, 8, 1};
 
 struct ArrayRef {
     int dtype;      // NIN_I64 / NIN_F64
@@ -288,7 +290,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
     std::vector<int32_t> hex8_list;
     const bool use_group = getenv("NIN_GLS_NO_GROUP") == nullptr;   // debugging switch: force the generic kernel
     const bool force_global = getenv("NIN_GLS_FORCE_GLOBAL") != nullptr;   // testing switch: systems in global scratch
-    int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0};
+    int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0}, cols_max[kGlsClasses] = {0};
     for (int64_t p = 0; p < P; ++p) {
         const int64_t ne = h.esup_ptr[p + 1] - h.esup_ptr[p], nf = h.fsup_ptr[p + 1] - h.fsup_ptr[p];
         int64_t nbf = 0;
@@ -299,15 +301,17 @@ int nin_grid_to_device(nin_grid *g, int device) {
             continue;
         }
         const int64_t m = ne + 3 * (nf - nbf) + nbf, n = 3 * ne + 1;
-        const int64_t doubles = ((ne + 1) >> 1) + n + m * n;
-        const int64_t bytes = ((doubles * 8 + 15) / 16) * 16;
         int c = kGlsClasses - 1;
-        for (int k = 0; k < kGlsClasses - 1 && !force_global; ++k)
-            if (bytes <= kClassBudget[k]) { c = k; break; }
+        int64_t bytes = ((((ne + 1) >> 1) + n + m * n) * 8 + 15) / 16 * 16;   // the scratch slot of the wave kernel
+        for (int k = 0; k < kGlsClasses - 1 && !force_global && n <= 256; ++k) {
+            const int64_t need = gls_block_lds_bytes(ne, m, n, kClassWaves[k]);
+            if (need <= kClassBudget[k]) { c = k; bytes = need; break; }
+        }
         g->node_class[p] = (uint8_t)c;
         lists[c].push_back((int32_t)p);
         need_max[c] = std::max(need_max[c], bytes);
         rows_max[c] = std::max(rows_max[c], m);
+        cols_max[c] = std::max(cols_max[c], n);
     }
     for (int c = 0; c < kGlsClasses; ++c) {
         auto &k = d.gls[c];
@@ -315,6 +319,9 @@ int nin_grid_to_device(nin_grid *g, int device) {
         k.lds_bytes = c == kGlsClasses - 1 ? 0 : (int32_t)need_max[c];
         k.rows_per_lane = (int32_t)std::max<int64_t>(1, (rows_max[c] + 63) / 64);
         k.max_rows = (int32_t)rows_max[c];
+        k.max_cols = (int32_t)cols_max[c];
+        k.waves = kClassWaves[c];
+        k.col_slots = (int32_t)std::max<int64_t>(1, (cols_max[c] + 63) / 64);
         const int32_t *lp = nullptr;
         if (k.count && (rc = dev_upload(d, &lp, lists[c]))) return rc;
         k.nodes = const_cast<int32_t *>(lp);
@@ -364,6 +371,16 @@ int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_m
     return NIN_OK;
 }
 
+// one GLS size class: the block kernel with the system in LDS, or the wave kernel on global scratch
+static int launch_class(DeviceGrid &d, int c, const int32_t *nodes, int32_t count, int add_neumann, double *out,
+                        double *nws, hipStream_t stream) {
+    const auto &k = d.gls[c];
+    if (c < kGlsClasses - 1)
+        return launch_gls_block(d.v, nodes, count, k.waves, k.col_slots, k.lds_bytes, add_neumann, out, nws, stream);
+    return launch_gls_class(d.v, nodes, count, 0, k.rows_per_lane, add_neumann, out, nws, d.gls_scratch,
+                            d.gls_scratch_stride, d.gls_scratch_slots, stream);
+}
+
 int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t n_targets, int add_neumann,
                        double *dev_csr_data, double *dev_neumann_ws, void *stream_) {
     if (!g || !dev_csr_data || !dev_neumann_ws) return fail(NIN_EINVAL, "NULL argument");
@@ -385,9 +402,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else {
             rc = launch_gls_hex8(d.v, d.hex8.nodes, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             for (int c = 0; c < kGlsClasses && !rc; ++c) {
-                auto &k = d.gls[c];
-                rc = launch_gls_class(d.v, k.nodes, k.count, k.lds_bytes, k.rows_per_lane, add_neumann, dev_csr_data,
-                                      dev_neumann_ws, d.gls_scratch, d.gls_scratch_stride, d.gls_scratch_slots, stream);
+                rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             }
         }
         if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -415,8 +430,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_gls_hex8(d.v, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
-        else rc = launch_gls_class(d.v, dl, cnt, d.gls[c].lds_bytes, d.gls[c].rows_per_lane, add_neumann, dev_csr_data,
-                                   dev_neumann_ws, d.gls_scratch, d.gls_scratch_stride, d.gls_scratch_slots, stream);
+        else rc = launch_class(d, (int)c, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         HIP_TRY(hipFreeAsync(dl, stream));
     }
     if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));

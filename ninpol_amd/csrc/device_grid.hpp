@@ -26,7 +26,7 @@ struct GridView {  // passed to kernels by value
     const uint8_t *flags;      // [P]       bit0 boundary_points, bit1 neumann flag
 };
 
-constexpr int kGlsClasses = 6;  // per-wave LDS budget classes + one global-scratch class
+constexpr int kGlsClasses = 5;  // four LDS budget classes (1 / 2 / 4 / 8 waves per node) + one global-scratch class
 
 struct DeviceGrid {
     int device = -1;
@@ -39,8 +39,10 @@ struct DeviceGrid {
     struct GlsClass {
         int32_t count = 0;
         int32_t *nodes = nullptr;  // device list (ascending node ids)
-        int32_t lds_bytes = 0;     // per wave
-        int32_t rows_per_lane = 1; // ceil(max rows / 64)
+        int32_t lds_bytes = 0;     // per node (workgroup)
+        int32_t waves = 1;         // wavefronts per node
+        int32_t col_slots = 1;     // ceil(max columns / 64)
+        int32_t rows_per_lane = 1; // ceil(max rows / 64): the wave kernel of the scratch class
         int32_t max_cells = 0, max_cols = 0, max_rows = 0;
     } gls[kGlsClasses];
     GlsClass hex8;  // nodes with exactly 8 cells and 12 faces, all internal: kernels_gls_group.hip

@@ -1,4 +1,6 @@
-// kernels_gls.hip -- GLS weights, gfx950: one node per wavefront.
+// kernels_gls.hip -- GLS weights, gfx950: one node per wavefront, the system in a global-memory scratch slot.
+// This is the fallback for nodes whose system does not fit the LDS of one CU (more than ~85 cells around a
+// node); everything else runs in kernels_gls_block.hip (LDS) or kernels_gls_group.hip (registers).
 //
 // What the reference does per node (gls.pyx:161-219): assemble the dense m x n system
 //   M = [ d_i^T on block i | 1 ]        n_elem rows    (x_K - x_v, gls.pyx:269-281)
@@ -284,30 +286,11 @@ __global__ __launch_bounds__(256) void nin_gls_wave_kernel(GridView g, const int
 }
 
 template <int RPL>
-int launch_rpl(bool lds, const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes,
-               int add_neumann, double *out, double *nws, double *scratch, int64_t scratch_stride,
-               int32_t scratch_slots, hipStream_t stream) {
-    if (lds) {
-        int wpb = 4;
-        while (wpb > 1 && (int64_t)wpb * lds_bytes > 64 * 1024) wpb >>= 1;
-        const int wave_doubles = lds_bytes / 8;
-        int64_t blocks = ((int64_t)count + wpb - 1) / wpb;
-        const int64_t cap = 256 * 16;
-        if (blocks > cap) blocks = cap;
-        auto kern = nin_gls_wave_kernel<RPL, true>;
-        const size_t dyn = (size_t)wpb * lds_bytes;
-        if (dyn > 48 * 1024) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
-                return -3;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws,
-                           wave_doubles, (double *)nullptr, 0ll);
-    } else {
-        const int wpb = 1;
-        int64_t blocks = count < scratch_slots ? count : scratch_slots;
-        hipLaunchKernelGGL((nin_gls_wave_kernel<RPL, false>), dim3((unsigned)blocks), dim3(64 * wpb), 0, stream, g, nodes,
-                           count, add_neumann, out, nws, 0, scratch, (long long)scratch_stride);
-    }
+int launch_rpl(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out, double *nws,
+               double *scratch, int64_t scratch_stride, int32_t scratch_slots, hipStream_t stream) {
+    const int64_t blocks = count < scratch_slots ? count : scratch_slots;   // one wave, one scratch slot per block
+    hipLaunchKernelGGL((nin_gls_wave_kernel<RPL, false>), dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, count,
+                       add_neumann, out, nws, 0, scratch, (long long)scratch_stride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -317,9 +300,8 @@ int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int
                      int32_t rows_per_lane, int add_neumann, double *out, double *nws, double *scratch,
                      int64_t scratch_stride, int32_t scratch_slots, hipStream_t stream) {
     if (count <= 0) return 0;
-    const bool lds = lds_bytes > 0;
-#define NIN_RPL(R) \
-    return launch_rpl<R>(lds, g, nodes, count, lds_bytes, add_neumann, out, nws, scratch, scratch_stride, scratch_slots, stream)
+    (void)lds_bytes;   // systems that fit LDS go to kernels_gls_block.hip; this kernel serves the global-scratch class
+#define NIN_RPL(R) return launch_rpl<R>(g, nodes, count, add_neumann, out, nws, scratch, scratch_stride, scratch_slots, stream)
     if (rows_per_lane <= 1) { NIN_RPL(1); }
     if (rows_per_lane <= 2) { NIN_RPL(2); }
     if (rows_per_lane <= 4) { NIN_RPL(4); }

@@ -1,0 +1,523 @@
+// kernels_gls_block.hip -- GLS weights for nodes of any shape, gfx950: one node per workgroup of NW wavefronts.
+//
+// Same mathematics as kernels_gls.hip (the reference's dense m x n system of gls.pyx:252-416, Householder QR as in
+// dgels, only row n-1 of the solution kept, gls.pyx:466-472), laid out so that no dot product ever crosses lanes:
+//
+//   * the system lives in LDS row-major; a lane owns COLUMNS (column j sits in lane (n-1-j) % 64, slot (n-1-j) / 64,
+//     so the columns still alive at step k always fill the low lanes) and wave w owns the ROWS i = w (mod NW);
+//   * the reflector is kept unnormalised, H = I - v v^T / (beta (beta - alpha)), v = x - beta e_k, so everything
+//     step k needs are the dots d_j = x . a_j of the raw pivot column with every live column (d_k is its squared
+//     norm): beta = -sign(alpha) sqrt(d_k), w_j = (d_j - beta a_kj) / (d_k + |alpha| sqrt(d_k)), a_ij -= x_i w_j;
+//   * one sweep per step: a wave walks its rows once, reads each element from LDS, updates it, writes it back and
+//     in the same breath accumulates the dots step k+1 will need.  x_i and the next pivot-column entry are picked
+//     out of the lane that owns them with v_readlane (the pivot lane is wave-uniform), so the row loop is
+//     ds_read, fma, ds_write, fma per element with no reduction and no broadcast traffic;
+//   * the per-wave partial dots meet in LDS (double-buffered), one workgroup barrier per step.
+//
+// R is left in the rows 0..n-2 of the LDS array; the weights are r_i / (r.r) with r the residual of the last
+// column c against the others (kernels_gls.hip): back-substitute R y = (Q^T c)(0:n-1), then
+// r_i = 1 - (x_Ki - x_v) . y_i for the n_elem cell rows and r.r = |(Q^T c)(n-1:m)|^2.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "device_grid.hpp"
+#include "launch.hpp"
+
+namespace nin {
+
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+__device__ __forceinline__ int ufirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+    double e = fma(-s * y, y, 1.0);
+    y = fma(y * e, fma(e, 0.375, 0.5), y);
+    e = fma(-s * y, y, 1.0);
+    y = fma(y * e, 0.5, y);
+    return y;
+}
+
+// Orders LDS traffic between the waves of the workgroup (or inside the single wave when NW == 1).
+template <int NW>
+__device__ __forceinline__ void group_sync() {
+    if (NW == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// Diagnostic build (-DNIN_BLOCK_STAMPS, tools/stamps_block.py): block 0 records s_memtime at four points of every
+// step into the neumann_ws array instead of the result.
+#ifdef NIN_BLOCK_STAMPS
+#define NIN_STAMP(S, K, J)                                                                        \
+    do {                                                                                          \
+        if ((S).stamps && (S).lane == 0) {                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            (S).stamps[(((S).wave * 256) + (K)) * 4 + (J)] = (double)__builtin_amdgcn_s_memtime(); \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                         \
+    } while (0)
+#else
+#define NIN_STAMP(S, K, J) do { } while (0)
+#endif
+
+struct Sys {       // one node's system, wave-uniform
+    double *A;     // [m][n] row-major
+    double *aux;   // partial dots [2][NW][n]; later y[n] and the weight row
+    int n, m, lane, wave;
+    double *stamps;
+};
+
+// Dots of column 0 with every column, over this wave's rows: what step 0 starts from.
+template <int NW, int CS, int TOP>
+__device__ __forceinline__ void first_dots(const Sys &s, double (&dn)[CS]) {
+    const int l0 = (s.n - 1) & 63;
+    for (int i = s.wave; i < s.m; i += NW) {
+        double own[TOP + 1];
+#pragma unroll
+        for (int q = 0; q <= TOP; ++q) {
+            const int jj = s.lane + 64 * q;
+            own[q] = jj < s.n ? s.A[i * s.n + (s.n - 1 - jj)] : 0.0;
+        }
+        const double x = readlane_f64(own[TOP], l0);
+#pragma unroll
+        for (int q = 0; q <= TOP; ++q) dn[q] = fma(x, own[q], dn[q]);
+    }
+}
+
+// Householder step k.  TOP = slot of the pivot column (the highest slot with a live column).
+template <int NW, int CS, int TOP, bool DB>
+__device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&dn)[CS], double (&rkeep)[CS],
+                                        bool &singular) {
+    const int n = s.n, m = s.m, lane = s.lane;
+    const int jjk = n - 1 - k, lk = jjk & 63;          // the pivot column's reversed index and lane
+    const int jjn = jjk - 1, ln = jjn & 63;            // column k + 1: same slot, or lane 63 of the slot below
+    const bool next_in_top = (jjn >> 6) == TOP;
+    double d[TOP + 1], rowk[TOP + 1], w[TOP + 1];
+    bool live[TOP + 1], upd[TOP + 1];
+#pragma unroll
+    for (int q = 0; q <= TOP; ++q) {
+        const int jj = lane + 64 * q;
+        live[q] = jj <= jjk;
+        upd[q] = jj < jjk;
+        if (NW == 1) {
+            d[q] = dn[q];
+        } else {
+            const double *P = s.aux + ((DB ? buf : 0) * NW * n + (jj < n ? jj : n - 1));   // dead lanes: any valid word
+            double part[NW];
+#pragma unroll
+            for (int u = 0; u < NW; ++u) part[u] = P[u * n];
+            double acc = part[0];
+#pragma unroll
+            for (int u = 1; u < NW; ++u) acc += part[u];
+            d[q] = acc;
+        }
+        rowk[q] = live[q] ? s.A[k * n + (n - 1 - jj)] : 0.0;
+        dn[q] = 0.0;
+    }
+    if (NW > 1 && !DB) group_sync<NW>();   // one partial buffer: nobody may publish before everybody has read
+    NIN_STAMP(s, k, 0);
+    const double dk = readlane_f64(d[TOP], lk), alpha = readlane_f64(rowk[TOP], lk);
+    if (!(dk != 0.0)) singular = true;                  // an all-zero pivot column (or NaN): no solution row
+    const double sq = dk * fast_rsqrt(dk);              // sqrt(d_k) = |(alpha, x)|
+    const double beta = -copysign(sq, alpha);
+    const double inv = fast_rcp(fma(fabs(alpha), sq, dk));   // 1 / (beta (beta - alpha))
+    const double vk = alpha - beta;
+#pragma unroll
+    for (int q = 0; q <= TOP; ++q) {
+        w[q] = upd[q] ? (d[q] - beta * rowk[q]) * inv : 0.0;
+        rkeep[q] = fma(-vk, w[q], rowk[q]);             // row k of R (written once no wave can still be reading row k)
+        if (q == TOP && lane == lk) rkeep[q] = beta;
+    }
+#pragma unroll
+    for (int q = TOP + 1; q < CS; ++q) rkeep[q] = 0.0;
+
+    NIN_STAMP(s, k, 1);
+    // The sweep: rows i > k of this wave in groups of G, the next group's loads in flight while this one is
+    // worked on.  Row slots past the end point at the all-zero row m (0 in, 0 out), and so do the dead lanes of
+    // the top slot, so the loop has no tail and no per-row masks.
+    constexpr int G = TOP == 0 ? 8 : 4;
+    const int i0 = k + 1 + ((s.wave - (k + 1)) % NW + NW) % NW;
+    const int groups = i0 < m ? ((m - i0 + NW - 1) / NW + G - 1) / G : 0;
+    const int zoff8 = m * n * 8;                     // byte offsets: one v_add per cell
+    char *const Ab = reinterpret_cast<char *>(s.A);
+    char *colp[TOP + 1];                             // this lane's column in row 0, per slot
+#pragma unroll
+    for (int q = 0; q <= TOP; ++q) colp[q] = Ab + (n - 1 - lane - 64 * q) * 8;
+    if (TOP > 0) colp[TOP] = live[TOP] ? colp[TOP] : Ab + lane * 8;
+    auto cell = [&](int t, int q) -> double * {
+        const int r = i0 + t * NW;
+        const int ro8 = r < m ? r * n * 8 : zoff8;   // wave-uniform
+        return reinterpret_cast<double *>(colp[q] + ((TOP > 0 && q == TOP && !live[q]) ? zoff8 : ro8));
+    };
+    if (TOP > 0 || live[0]) {
+        double cur[G][TOP + 1], acc[2][TOP + 1];
+        double *ca[G][TOP + 1];
+#pragma unroll
+        for (int q = 0; q <= TOP; ++q) acc[0][q] = acc[1][q] = 0.0;
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+            for (int q = 0; q <= TOP; ++q) {
+                ca[u][q] = cell(u, q);
+                cur[u][q] = *ca[u][q];
+            }
+        for (int g = 0; g < groups; ++g) {
+            double nx[G][TOP + 1];
+            double *na[G][TOP + 1];
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int q = 0; q <= TOP; ++q) {
+                    na[u][q] = cell((g + 1) * G + u, q);
+                    nx[u][q] = *na[u][q];
+                }
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const double x = readlane_f64(cur[u][TOP], lk);
+                double nv[TOP + 1];
+#pragma unroll
+                for (int q = 0; q <= TOP; ++q) {
+                    nv[q] = fma(-x, w[q], cur[u][q]);
+                    *ca[u][q] = nv[q];
+                }
+                const double xn = readlane_f64(next_in_top ? nv[TOP] : nv[TOP > 0 ? TOP - 1 : 0], ln);
+#pragma unroll
+                for (int q = 0; q <= TOP; ++q) acc[u & 1][q] = fma(xn, nv[q], acc[u & 1][q]);
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+                for (int q = 0; q <= TOP; ++q) {
+                    cur[u][q] = nx[u][q];
+                    ca[u][q] = na[u][q];
+                }
+        }
+#pragma unroll
+        for (int q = 0; q <= TOP; ++q) dn[q] = acc[0][q] + acc[1][q];
+    }
+    NIN_STAMP(s, k, 2);
+    if (NW > 1) {
+        double *P = s.aux + ((size_t)(DB ? (buf ^ 1) : 0) * NW + s.wave) * n;
+#pragma unroll
+        for (int q = 0; q <= TOP; ++q)
+            if (upd[q]) P[lane + 64 * q] = dn[q];
+    }
+}
+
+template <int NW, int CS>
+__global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, const int32_t *__restrict__ nodes,
+                                                                 int32_t count, int add_neumann,
+                                                                 double *__restrict__ out, double *__restrict__ nws,
+                                                                 int dbg) {
+    extern __shared__ double smem[];
+    (void)dbg;
+    constexpr bool DB = NW != 4;   // partial dots double-buffered (one barrier per step) except where LDS is tight
+    const int tid = threadIdx.x, nthr = 64 * NW;
+    const int lane = tid & 63;
+    const int wave = ufirst(tid >> 6);
+
+    for (int32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
+        const int32_t p = ufirst(nodes ? nodes[idx] : idx);
+        const int32_t eb = ufirst(g.esup_ptr[p]), ne = ufirst(g.esup_ptr[p + 1]) - eb;
+        const int32_t fb = ufirst(g.fsup_ptr[p]), nf = ufirst(g.fsup_ptr[p + 1]) - fb;
+        const int fl = ufirst((int)g.flags[p]);
+        const bool is_neu = (fl & 2) != 0;
+
+        int n_if = 0;   // internal faces of the node (n_esuf == 2, gls.pyx:293-296); every wave counts them itself
+        for (int f0 = 0; f0 < nf; f0 += 64) {
+            const int fi = f0 + lane;
+            const bool internal = fi < nf && g.face_cells[2 * (size_t)g.fsup[fb + fi] + 1] >= 0;
+            n_if += __popcll(__ballot(internal));
+        }
+        const int n_bf = nf - n_if;
+        const int n = 3 * ne + 1;
+        const int m = ne + 3 * n_if + (is_neu ? n_bf : 0);
+        // Dirichlet boundary node (gls.pyx:165-166), n_bface >= n_face (gls.pyx:266-267), or fewer rows than
+        // unknowns next to the node value: zero row.
+        if (((fl & 1) && !is_neu) || n_if == 0 || m < n - 1) {
+            for (int i = tid; i < ne; i += nthr) out[eb + i] = 0.0;
+#ifdef NIN_BLOCK_STAMPS
+            if (tid == 0 && (dbg >> 8) == 0) nws[p] = 0.0;
+#else
+            if (tid == 0) nws[p] = 0.0;
+#endif
+            continue;
+        }
+        Sys s;
+        s.A = smem;
+        s.aux = smem + (size_t)(m + 1) * n;   // row m stays zero: the sweep's parking row
+        s.n = n; s.m = m; s.lane = lane; s.wave = wave;
+#ifdef NIN_BLOCK_STAMPS
+        s.stamps = (dbg >> 8) == p ? nws : nullptr;   // NIN_GLS_BLOCK_DEBUG = node << 8: that node's block records
+#else
+        s.stamps = nullptr;
+#endif
+        int32_t *cells = reinterpret_cast<int32_t *>(s.aux + (NW == 1 ? 2 : (DB ? 2 : 1) * NW) * n);
+
+        for (int i = tid; i < (m + 1) * n; i += nthr) s.A[i] = 0.0;
+        for (int i = tid; i < ne; i += nthr) cells[i] = g.esup[eb + i];
+        group_sync<NW>();
+
+        const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1],
+                     xv2 = g.coords[3 * (size_t)p + 2];
+        if (wave == (NW > 1 ? 1 : 0)) {
+            // cell rows: [x_K - x_v] on the cell's own block, 1 in the last column (gls.pyx:269-281)
+            for (int i = lane; i < ne; i += 64) {
+                const size_t c = (size_t)cells[i];
+                double *row = s.A + (size_t)i * n;
+                row[3 * i + 0] = g.centroids[3 * c + 0] - xv0;
+                row[3 * i + 1] = g.centroids[3 * c + 1] - xv1;
+                row[3 * i + 2] = g.centroids[3 * c + 2] - xv2;
+                row[n - 1] = 1.0;
+            }
+        }
+        if (wave == 0) {
+            int if_base = 0, bf_base = 0;
+            for (int f0 = 0; f0 < nf; f0 += 64) {
+                const int fi = f0 + lane;
+                const bool valid = fi < nf;
+                const size_t f = valid ? (size_t)g.fsup[fb + fi] : 0;
+                const int ca = valid ? g.face_cells[2 * f] : 0, cb = valid ? g.face_cells[2 * f + 1] : -1;
+                const bool internal = valid && cb >= 0;
+                const bool bface = valid && cb < 0;
+                const unsigned long long mi = __ballot(internal), mb = __ballot(bface);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (internal) {
+                    const int row = ne + 3 * (if_base + __popcll(mi & below));
+                    const double N0 = g.face_normal[3 * f + 0], N1 = g.face_normal[3 * f + 1], N2 = g.face_normal[3 * f + 2];
+                    const double T0 = xv0 - g.face_center[3 * f + 0], T1 = xv1 - g.face_center[3 * f + 1],
+                                 T2 = xv2 - g.face_center[3 * f + 2];
+                    // T_sj2 = N x T_sj1, tau = |T_sj2|^(-eta), eta = max diff_mag of the two cells (gls.pyx:304-318)
+                    const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+                    const double da = g.diff_mag[ca], db = g.diff_mag[cb];
+                    double eta = 0.0;
+                    eta = da > eta ? da : eta;
+                    eta = db > eta ? db : eta;
+                    const double tj = pow(sqrt(U0 * U0 + U1 * U1 + U2 * U2), -eta);
+                    const double *Ka = g.perm + 9 * (size_t)ca, *Kb = g.perm + 9 * (size_t)cb;
+                    int Ia = 0, Ib = 0;
+                    for (int q = 0; q < ne; ++q) {
+                        const int cq = cells[q];
+                        Ia = cq == ca ? q : Ia;
+                        Ib = cq == cb ? q : Ib;
+                    }
+                    double *r0 = s.A + (size_t)row * n;   // rows row, row+1, row+2 = K N, T1, tau T2
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double nLa = Ka[c * 3 + 0] * N0 + Ka[c * 3 + 1] * N1 + Ka[c * 3 + 2] * N2;  // row c of K . N
+                        const double nLb = Kb[c * 3 + 0] * N0 + Kb[c * 3 + 1] * N1 + Kb[c * 3 + 2] * N2;
+                        const double t1 = c == 0 ? T0 : (c == 1 ? T1 : T2);
+                        const double u = tj * (c == 0 ? U0 : (c == 1 ? U1 : U2));
+                        r0[3 * Ia + c] = -nLa;        r0[3 * Ib + c] = nLb;
+                        r0[n + 3 * Ia + c] = -t1;     r0[n + 3 * Ib + c] = t1;
+                        r0[2 * n + 3 * Ia + c] = -u;  r0[2 * n + 3 * Ib + c] = u;
+                    }
+                }
+                if (bface && is_neu) {  // set_neumann_rows, gls.pyx:394-416 (its RHS column is never read back)
+                    const int row = ne + 3 * n_if + bf_base + __popcll(mb & below);
+                    const double N0 = g.face_normal[3 * f + 0], N1 = g.face_normal[3 * f + 1], N2 = g.face_normal[3 * f + 2];
+                    const double *Ka = g.perm + 9 * (size_t)ca;
+                    int Ia = 0;
+                    for (int q = 0; q < ne; ++q) Ia = cells[q] == ca ? q : Ia;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        s.A[(size_t)row * n + 3 * Ia + c] = -(Ka[c * 3 + 0] * N0 + Ka[c * 3 + 1] * N1 + Ka[c * 3 + 2] * N2);
+                }
+                if_base += __popcll(mi);
+                bf_base += __popcll(mb);
+            }
+        }
+        group_sync<NW>();
+
+        // ---- Householder QR of the first n-1 columns, the last one carried along -----------------------------
+        bool singular = false;
+        double dn[CS], rkeep[CS];
+#pragma unroll
+        for (int q = 0; q < CS; ++q) { dn[q] = 0.0; rkeep[q] = 0.0; }
+        {
+            const int top0 = (n - 1) >> 6;
+#define NIN_TOP(T) if (CS > T && top0 == T) first_dots<NW, CS, T>(s, dn)
+            NIN_TOP(0); NIN_TOP(1); NIN_TOP(2); NIN_TOP(3);
+#undef NIN_TOP
+        }
+        int buf = 0;
+        if (NW > 1) {
+            double *P = s.aux + (size_t)wave * n;
+#pragma unroll
+            for (int q = 0; q < CS; ++q)
+                if (lane + 64 * q < n) P[lane + 64 * q] = dn[q];
+            group_sync<NW>();
+        }
+        for (int k = 0; k < n - 1; ++k) {
+            if (k > 0 && wave == (k - 1) % NW) {   // row k-1 of R: every wave has finished reading it as a pivot row
+                double *row = s.A + (size_t)(k - 1) * n;
+#pragma unroll
+                for (int q = 0; q < CS; ++q) {
+                    const int jj = lane + 64 * q;
+                    if (jj <= n - k) row[n - 1 - jj] = rkeep[q];
+                }
+            }
+            const int top = (n - 1 - k) >> 6;
+#define NIN_TOP(T) if (CS > T && top == T) qr_step<NW, CS, T, DB>(s, k, buf, dn, rkeep, singular)
+            NIN_TOP(0); NIN_TOP(1); NIN_TOP(2); NIN_TOP(3);
+#undef NIN_TOP
+            if (NW > 1) {
+                group_sync<NW>();
+                if (DB) buf ^= 1;
+            }
+            NIN_STAMP(s, k, 3);
+        }
+        if (wave == (n - 2) % NW) {
+            double *row = s.A + (size_t)(n - 2) * n;
+            if (lane <= 1) row[n - 1 - lane] = rkeep[0];
+        }
+        group_sync<NW>();
+
+        // ---- tail, wave 0: R y = c~(0:n-1) by columns (lane = row), then the residual ------------------------
+        if (wave == 0) {
+            double ct[CS];
+#pragma unroll
+            for (int q = 0; q < CS; ++q) {
+                const int i = lane + 64 * q;
+                ct[q] = i < n - 1 ? s.A[(size_t)i * n + (n - 1)] : 0.0;
+            }
+            double *y = s.aux, *wrow = s.aux + n;
+            for (int k = n - 2; k >= 0; --k) {
+                const int ks = k >> 6, kl = k & 63;
+                double col[CS];
+                double rkk = 1.0, ck = 0.0;
+#pragma unroll
+                for (int q = 0; q < CS; ++q) {
+                    const int i = lane + 64 * q;
+                    col[q] = (q <= ks && i <= k) ? s.A[(size_t)i * n + k] : 0.0;
+                    if (q == ks) {
+                        rkk = readlane_f64(col[q], kl);
+                        ck = readlane_f64(ct[q], kl);
+                    }
+                }
+                const double yk = ck * fast_rcp(rkk);
+#pragma unroll
+                for (int q = 0; q < CS; ++q) ct[q] = fma(-yk, col[q], ct[q]);
+                if (lane == 0) y[k] = yk;
+            }
+            double rr = 0.0;
+            for (int i = n - 1 + lane; i < m; i += 64) {
+                const double c = s.A[(size_t)i * n + (n - 1)];
+                rr = fma(c, c, rr);
+            }
+            rr = wave_sum(rr);
+            group_sync<1>();
+            singular = singular || !(rr > 0.0);
+            const double irr = 1.0 / rr;
+            for (int i = lane; i < ne; i += 64) {
+                const double *row = s.A;   // the cell rows were consumed by the QR: rebuild x_K - x_v as assembled
+                (void)row;
+                const size_t c = (size_t)cells[i];
+                const double d0 = g.centroids[3 * c + 0] - xv0, d1 = g.centroids[3 * c + 1] - xv1,
+                             d2 = g.centroids[3 * c + 2] - xv2;
+                const double r = 1.0 - (d0 * y[3 * i + 0] + d1 * y[3 * i + 1] + d2 * y[3 * i + 2]);
+                wrow[i] = singular ? 0.0 : r * irr;
+            }
+            group_sync<1>();
+            // gls.pyx:470-472: neumann_ws = solution entry (n-1, n_elem-1), i.e. the LAST cell's weight
+            const double nwv = is_neu ? wrow[ne - 1] : 0.0;
+            const double add = add_neumann ? nwv : 0.0;
+            for (int i = lane; i < ne; i += 64) out[eb + i] = wrow[i] + add;
+#ifdef NIN_BLOCK_STAMPS
+            if (lane == 0 && (dbg >> 8) == 0) nws[p] = nwv;
+#else
+            if (lane == 0) nws[p] = nwv;
+#endif
+        }
+        group_sync<NW>();   // the next node reuses the LDS
+    }
+}
+
+template <int NW, int CS>
+int launch_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes, int add_neumann,
+                 double *out, double *nws, hipStream_t stream) {
+    auto kern = nin_gls_block_kernel<NW, CS>;
+    static const int dbg = getenv("NIN_GLS_BLOCK_DEBUG") ? atoi(getenv("NIN_GLS_BLOCK_DEBUG")) : 0;
+    if (lds_bytes > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return -3;
+    }
+    int per_cu = (160 * 1024) / (lds_bytes < 1024 ? 1024 : lds_bytes);
+    const int wave_cap = 32 / NW;
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = (int64_t)256 * per_cu * 2;
+    if (blocks > count) blocks = count;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), (size_t)lds_bytes, stream, g, nodes, count, add_neumann,
+                       out, nws, dbg);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int NW>
+int launch_block_cs(int cs, const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes, int add_neumann,
+                    double *out, double *nws, hipStream_t stream) {
+    switch (cs) {
+        case 1: return launch_block<NW, 1>(g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+        case 2: return launch_block<NW, 2>(g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+        case 3: return launch_block<NW, 3>(g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+        case 4: return launch_block<NW, 4>(g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+    }
+    return -5;
+}
+
+}  // namespace
+
+int64_t gls_block_lds_bytes(int64_t ne, int64_t m, int64_t n, int waves) {
+    const int64_t doubles = (m + 1) * n + (waves == 1 ? 2 : (waves != 4 ? 2 : 1) * waves) * n + ((ne + 1) >> 1);
+    return ((doubles * 8 + 15) / 16) * 16;
+}
+
+int launch_gls_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t waves, int32_t col_slots,
+                     int32_t lds_bytes, int add_neumann, double *out, double *nws, hipStream_t stream) {
+    if (count <= 0) return 0;
+    switch (waves) {
+        case 1: return launch_block_cs<1>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+        case 2: return launch_block_cs<2>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+        case 4: return launch_block_cs<4>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+        case 8: return launch_block_cs<8>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+    }
+    return -1;
+}
+
+const char *kernel_name_gls_block() { return "nin_gls_block_kernel"; }
+
+}  // namespace nin

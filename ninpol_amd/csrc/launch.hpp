@@ -18,6 +18,11 @@ int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, int3
 int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes,
                      int32_t rows_per_lane, int add_neumann, double *out, double *nws,
                      double *scratch, int64_t scratch_stride, int32_t scratch_slots, hipStream_t stream);
+// the block kernel (kernels_gls_block.hip): one node per workgroup of `waves` wavefronts, system in LDS
+int64_t gls_block_lds_bytes(int64_t ne, int64_t m, int64_t n, int waves);
+int launch_gls_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t waves, int32_t col_slots,
+                     int32_t lds_bytes, int add_neumann, double *out, double *nws, hipStream_t stream);
+const char *kernel_name_gls_block();
 // the register-resident group kernel for (8 cells, 12 internal faces) nodes, kernels_gls_group.hip
 int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out,
                     double *nws, hipStream_t stream);
