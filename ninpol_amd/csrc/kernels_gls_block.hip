@@ -3,8 +3,11 @@
 // Same mathematics as kernels_gls.hip (the reference's dense m x n system of gls.pyx:252-416, Householder QR as in
 // dgels, only row n-1 of the solution kept, gls.pyx:466-472), laid out so that no dot product ever crosses lanes:
 //
-//   * the system lives in LDS row-major; a lane owns COLUMNS (column j sits in lane (n-1-j) % 64, slot (n-1-j) / 64,
-//     so the columns still alive at step k always fill the low lanes) and wave w owns the ROWS i = w (mod NW);
+//   * a lane owns COLUMNS (column j sits in lane (n-1-j) % 64, slot (n-1-j) / 64, so the columns still alive at
+//     step k always fill the low lanes) and wave w owns the ROWS i = w (mod NW).  The system lives in LDS
+//     column-major with an odd column pitch: a wave's access to one row is conflict-free, and inside a lane's
+//     column the rows of a wave sit at compile-time distances, so the row loop needs no address arithmetic
+//     (ds_read / ds_write immediates);
 //   * the reflector is kept unnormalised, H = I - v v^T / (beta (beta - alpha)), v = x - beta e_k, so everything
 //     step k needs are the dots d_j = x . a_j of the raw pivot column with every live column (d_k is its squared
 //     norm): beta = -sign(alpha) sqrt(d_k), w_j = (d_j - beta a_kj) / (d_k + |alpha| sqrt(d_k)), a_ij -= x_i w_j;
@@ -95,23 +98,28 @@ __device__ __forceinline__ void group_sync() {
 #endif
 
 struct Sys {       // one node's system, wave-uniform
-    double *A;     // [m][n] row-major
+    double *A;     // [n + 1][ld] column-major, ld odd >= m; column n stays zero (parking column for dead lanes)
     double *aux;   // partial dots [2][NW][n]; later y[n] and the weight row
-    int n, m, lane, wave;
+    int n, m, ld, lane, wave;
     double *stamps;
 };
+
+// This lane's column in slot q (nullptr-free: lanes without a column get the parking column).
+__device__ __forceinline__ double *lane_column(const Sys &s, int q, bool has) {
+    return s.A + (has ? (s.n - 1 - (s.lane + 64 * q)) : s.n) * s.ld;
+}
 
 // Dots of column 0 with every column, over this wave's rows: what step 0 starts from.
 template <int NW, int CS, int TOP>
 __device__ __forceinline__ void first_dots(const Sys &s, double (&dn)[CS]) {
     const int l0 = (s.n - 1) & 63;
+    const double *col[TOP + 1];
+#pragma unroll
+    for (int q = 0; q <= TOP; ++q) col[q] = lane_column(s, q, s.lane + 64 * q < s.n);
     for (int i = s.wave; i < s.m; i += NW) {
         double own[TOP + 1];
 #pragma unroll
-        for (int q = 0; q <= TOP; ++q) {
-            const int jj = s.lane + 64 * q;
-            own[q] = jj < s.n ? s.A[i * s.n + (s.n - 1 - jj)] : 0.0;
-        }
+        for (int q = 0; q <= TOP; ++q) own[q] = col[q][i];
         const double x = readlane_f64(own[TOP], l0);
 #pragma unroll
         for (int q = 0; q <= TOP; ++q) dn[q] = fma(x, own[q], dn[q]);
@@ -127,6 +135,7 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
     const int jjn = jjk - 1, ln = jjn & 63;            // column k + 1: same slot, or lane 63 of the slot below
     const bool next_in_top = (jjn >> 6) == TOP;
     double d[TOP + 1], rowk[TOP + 1], w[TOP + 1];
+    double *col[TOP + 1];
     bool live[TOP + 1], upd[TOP + 1];
 #pragma unroll
     for (int q = 0; q <= TOP; ++q) {
@@ -145,7 +154,8 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
             for (int u = 1; u < NW; ++u) acc += part[u];
             d[q] = acc;
         }
-        rowk[q] = live[q] ? s.A[k * n + (n - 1 - jj)] : 0.0;
+        col[q] = lane_column(s, q, live[q]);
+        rowk[q] = col[q][k];          // dead lanes read the parking column: 0
         dn[q] = 0.0;
     }
     if (NW > 1 && !DB) group_sync<NW>();   // one partial buffer: nobody may publish before everybody has read
@@ -166,65 +176,73 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
     for (int q = TOP + 1; q < CS; ++q) rkeep[q] = 0.0;
 
     NIN_STAMP(s, k, 1);
-    // The sweep: rows i > k of this wave in groups of G, the next group's loads in flight while this one is
-    // worked on.  Row slots past the end point at the all-zero row m (0 in, 0 out), and so do the dead lanes of
-    // the top slot, so the loop has no tail and no per-row masks.
+    // The sweep: rows i0, i0 + NW, ... of this wave, G at a time with the next G loads in flight.  Inside a
+    // lane's column those rows are NW doubles apart: every access is base + immediate.  Dead lanes of the top
+    // slot work on the parking column (0 in, w = 0, 0 out); with a single slot they are simply masked off.
     constexpr int G = TOP == 0 ? 8 : 4;
     const int i0 = k + 1 + ((s.wave - (k + 1)) % NW + NW) % NW;
-    const int groups = i0 < m ? ((m - i0 + NW - 1) / NW + G - 1) / G : 0;
-    const int zoff8 = m * n * 8;                     // byte offsets: one v_add per cell
-    char *const Ab = reinterpret_cast<char *>(s.A);
-    char *colp[TOP + 1];                             // this lane's column in row 0, per slot
-#pragma unroll
-    for (int q = 0; q <= TOP; ++q) colp[q] = Ab + (n - 1 - lane - 64 * q) * 8;
-    if (TOP > 0) colp[TOP] = live[TOP] ? colp[TOP] : Ab + lane * 8;
-    auto cell = [&](int t, int q) -> double * {
-        const int r = i0 + t * NW;
-        const int ro8 = r < m ? r * n * 8 : zoff8;   // wave-uniform
-        return reinterpret_cast<double *>(colp[q] + ((TOP > 0 && q == TOP && !live[q]) ? zoff8 : ro8));
-    };
+    const int rows = i0 < m ? (m - i0 + NW - 1) / NW : 0;
+    const int full = rows / G, rem = rows % G;
     if (TOP > 0 || live[0]) {
-        double cur[G][TOP + 1], acc[2][TOP + 1];
-        double *ca[G][TOP + 1];
+        double acc[2][TOP + 1];
+        double *p[TOP + 1];
 #pragma unroll
-        for (int q = 0; q <= TOP; ++q) acc[0][q] = acc[1][q] = 0.0;
-#pragma unroll
-        for (int u = 0; u < G; ++u)
+        for (int q = 0; q <= TOP; ++q) {
+            acc[0][q] = acc[1][q] = 0.0;
+            p[q] = col[q] + i0;
+        }
+        auto row = [&](int u, double (&cur)[G][TOP + 1]) {
+            const double x = readlane_f64(cur[u][TOP], lk);
+            double nv[TOP + 1];
 #pragma unroll
             for (int q = 0; q <= TOP; ++q) {
-                ca[u][q] = cell(u, q);
-                cur[u][q] = *ca[u][q];
+                nv[q] = fma(-x, w[q], cur[u][q]);
+                p[q][u * NW] = nv[q];
             }
-        for (int g = 0; g < groups; ++g) {
-            double nx[G][TOP + 1];
-            double *na[G][TOP + 1];
+            const double xn = readlane_f64(next_in_top ? nv[TOP] : nv[TOP > 0 ? TOP - 1 : 0], ln);
 #pragma unroll
-            for (int u = 0; u < G; ++u)
-#pragma unroll
-                for (int q = 0; q <= TOP; ++q) {
-                    na[u][q] = cell((g + 1) * G + u, q);
-                    nx[u][q] = *na[u][q];
-                }
+            for (int q = 0; q <= TOP; ++q) acc[u & 1][q] = fma(xn, nv[q], acc[u & 1][q]);
+        };
+        if (full > 0) {
+            double cur[G][TOP + 1];
 #pragma unroll
             for (int u = 0; u < G; ++u) {
-                const double x = readlane_f64(cur[u][TOP], lk);
-                double nv[TOP + 1];
 #pragma unroll
-                for (int q = 0; q <= TOP; ++q) {
-                    nv[q] = fma(-x, w[q], cur[u][q]);
-                    *ca[u][q] = nv[q];
+                for (int q = 0; q <= TOP; ++q) cur[u][q] = p[q][u * NW];
+            }
+            for (int g = 1; g < full; ++g) {
+                double nx[G][TOP + 1];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+#pragma unroll
+                    for (int q = 0; q <= TOP; ++q) nx[u][q] = p[q][(G + u) * NW];
                 }
-                const double xn = readlane_f64(next_in_top ? nv[TOP] : nv[TOP > 0 ? TOP - 1 : 0], ln);
 #pragma unroll
-                for (int q = 0; q <= TOP; ++q) acc[u & 1][q] = fma(xn, nv[q], acc[u & 1][q]);
+                for (int u = 0; u < G; ++u) row(u, cur);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+#pragma unroll
+                    for (int q = 0; q <= TOP; ++q) cur[u][q] = nx[u][q];
+                }
+#pragma unroll
+                for (int q = 0; q <= TOP; ++q) p[q] += G * NW;
             }
 #pragma unroll
-            for (int u = 0; u < G; ++u)
+            for (int u = 0; u < G; ++u) row(u, cur);
 #pragma unroll
-                for (int q = 0; q <= TOP; ++q) {
-                    cur[u][q] = nx[u][q];
-                    ca[u][q] = na[u][q];
+            for (int q = 0; q <= TOP; ++q) p[q] += G * NW;
+        }
+        if (rem > 0) {   // the last, partial group (wave-uniform guards)
+            double cur[G][TOP + 1];
+#pragma unroll
+            for (int u = 0; u < G - 1; ++u)
+                if (u < rem) {
+#pragma unroll
+                    for (int q = 0; q <= TOP; ++q) cur[u][q] = p[q][u * NW];
                 }
+#pragma unroll
+            for (int u = 0; u < G - 1; ++u)
+                if (u < rem) row(u, cur);
         }
 #pragma unroll
         for (int q = 0; q <= TOP; ++q) dn[q] = acc[0][q] + acc[1][q];
@@ -278,9 +296,10 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             continue;
         }
         Sys s;
+        const int ld = m | 1;   // odd pitch: the 64 lanes of a row access hit 64 different 8-byte bank pairs
         s.A = smem;
-        s.aux = smem + (size_t)(m + 1) * n;   // row m stays zero: the sweep's parking row
-        s.n = n; s.m = m; s.lane = lane; s.wave = wave;
+        s.aux = smem + (size_t)(n + 1) * ld;
+        s.n = n; s.m = m; s.ld = ld; s.lane = lane; s.wave = wave;
 #ifdef NIN_BLOCK_STAMPS
         s.stamps = (dbg >> 8) == p ? nws : nullptr;   // NIN_GLS_BLOCK_DEBUG = node << 8: that node's block records
 #else
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
 #endif
         int32_t *cells = reinterpret_cast<int32_t *>(s.aux + (NW == 1 ? 2 : (DB ? 2 : 1) * NW) * n);
 
-        for (int i = tid; i < (m + 1) * n; i += nthr) s.A[i] = 0.0;
+        for (int i = tid; i < (n + 1) * ld; i += nthr) s.A[i] = 0.0;
         for (int i = tid; i < ne; i += nthr) cells[i] = g.esup[eb + i];
         group_sync<NW>();
 
@@ -298,11 +317,11 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             // cell rows: [x_K - x_v] on the cell's own block, 1 in the last column (gls.pyx:269-281)
             for (int i = lane; i < ne; i += 64) {
                 const size_t c = (size_t)cells[i];
-                double *row = s.A + (size_t)i * n;
-                row[3 * i + 0] = g.centroids[3 * c + 0] - xv0;
-                row[3 * i + 1] = g.centroids[3 * c + 1] - xv1;
-                row[3 * i + 2] = g.centroids[3 * c + 2] - xv2;
-                row[n - 1] = 1.0;
+                double *row = s.A + i;
+                row[(3 * i + 0) * ld] = g.centroids[3 * c + 0] - xv0;
+                row[(3 * i + 1) * ld] = g.centroids[3 * c + 1] - xv1;
+                row[(3 * i + 2) * ld] = g.centroids[3 * c + 2] - xv2;
+                row[(n - 1) * ld] = 1.0;
             }
         }
         if (wave == 0) {
@@ -335,16 +354,16 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                         Ia = cq == ca ? q : Ia;
                         Ib = cq == cb ? q : Ib;
                     }
-                    double *r0 = s.A + (size_t)row * n;   // rows row, row+1, row+2 = K N, T1, tau T2
+                    double *ra = s.A + (3 * Ia) * ld + row, *rb = s.A + (3 * Ib) * ld + row;   // rows row.. row+2 = K N, T1, tau T2
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const double nLa = Ka[c * 3 + 0] * N0 + Ka[c * 3 + 1] * N1 + Ka[c * 3 + 2] * N2;  // row c of K . N
                         const double nLb = Kb[c * 3 + 0] * N0 + Kb[c * 3 + 1] * N1 + Kb[c * 3 + 2] * N2;
                         const double t1 = c == 0 ? T0 : (c == 1 ? T1 : T2);
                         const double u = tj * (c == 0 ? U0 : (c == 1 ? U1 : U2));
-                        r0[3 * Ia + c] = -nLa;        r0[3 * Ib + c] = nLb;
-                        r0[n + 3 * Ia + c] = -t1;     r0[n + 3 * Ib + c] = t1;
-                        r0[2 * n + 3 * Ia + c] = -u;  r0[2 * n + 3 * Ib + c] = u;
+                        ra[c * ld + 0] = -nLa; rb[c * ld + 0] = nLb;
+                        ra[c * ld + 1] = -t1;  rb[c * ld + 1] = t1;
+                        ra[c * ld + 2] = -u;   rb[c * ld + 2] = u;
                     }
                 }
                 if (bface && is_neu) {  // set_neumann_rows, gls.pyx:394-416 (its RHS column is never read back)
@@ -355,7 +374,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                     for (int q = 0; q < ne; ++q) Ia = cells[q] == ca ? q : Ia;
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        s.A[(size_t)row * n + 3 * Ia + c] = -(Ka[c * 3 + 0] * N0 + Ka[c * 3 + 1] * N1 + Ka[c * 3 + 2] * N2);
+                        s.A[(3 * Ia + c) * ld + row] = -(Ka[c * 3 + 0] * N0 + Ka[c * 3 + 1] * N1 + Ka[c * 3 + 2] * N2);
                 }
                 if_base += __popcll(mi);
                 bf_base += __popcll(mb);
@@ -384,11 +403,10 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
         }
         for (int k = 0; k < n - 1; ++k) {
             if (k > 0 && wave == (k - 1) % NW) {   // row k-1 of R: every wave has finished reading it as a pivot row
-                double *row = s.A + (size_t)(k - 1) * n;
 #pragma unroll
                 for (int q = 0; q < CS; ++q) {
                     const int jj = lane + 64 * q;
-                    if (jj <= n - k) row[n - 1 - jj] = rkeep[q];
+                    if (jj <= n - k) s.A[(n - 1 - jj) * ld + (k - 1)] = rkeep[q];
                 }
             }
             const int top = (n - 1 - k) >> 6;
@@ -402,8 +420,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             NIN_STAMP(s, k, 3);
         }
         if (wave == (n - 2) % NW) {
-            double *row = s.A + (size_t)(n - 2) * n;
-            if (lane <= 1) row[n - 1 - lane] = rkeep[0];
+            if (lane <= 1) s.A[(n - 1 - lane) * ld + (n - 2)] = rkeep[0];
         }
         group_sync<NW>();
 
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
 #pragma unroll
             for (int q = 0; q < CS; ++q) {
                 const int i = lane + 64 * q;
-                ct[q] = i < n - 1 ? s.A[(size_t)i * n + (n - 1)] : 0.0;
+                ct[q] = i < n - 1 ? s.A[(n - 1) * ld + i] : 0.0;
             }
             double *y = s.aux, *wrow = s.aux + n;
             for (int k = n - 2; k >= 0; --k) {
@@ -423,7 +440,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
 #pragma unroll
                 for (int q = 0; q < CS; ++q) {
                     const int i = lane + 64 * q;
-                    col[q] = (q <= ks && i <= k) ? s.A[(size_t)i * n + k] : 0.0;
+                    col[q] = (q <= ks && i <= k) ? s.A[k * ld + i] : 0.0;
                     if (q == ks) {
                         rkk = readlane_f64(col[q], kl);
                         ck = readlane_f64(ct[q], kl);
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             }
             double rr = 0.0;
             for (int i = n - 1 + lane; i < m; i += 64) {
-                const double c = s.A[(size_t)i * n + (n - 1)];
+                const double c = s.A[(n - 1) * ld + i];
                 rr = fma(c, c, rr);
             }
             rr = wave_sum(rr);
@@ -482,6 +499,8 @@ int launch_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t
     if (per_cu < 1) per_cu = 1;
     int64_t blocks = (int64_t)256 * per_cu * 2;
     if (blocks > count) blocks = count;
+    static const int max_blocks = getenv("NIN_GLS_BLOCK_MAX_BLOCKS") ? atoi(getenv("NIN_GLS_BLOCK_MAX_BLOCKS")) : 0;
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;   // diagnostic: occupancy experiments
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), (size_t)lds_bytes, stream, g, nodes, count, add_neumann,
                        out, nws, dbg);
     return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -502,7 +521,7 @@ int launch_block_cs(int cs, const GridView &g, const int32_t *nodes, int32_t cou
 }  // namespace
 
 int64_t gls_block_lds_bytes(int64_t ne, int64_t m, int64_t n, int waves) {
-    const int64_t doubles = (m + 1) * n + (waves == 1 ? 2 : (waves != 4 ? 2 : 1) * waves) * n + ((ne + 1) >> 1);
+    const int64_t doubles = (n + 1) * (m | 1) + (waves == 1 ? 2 : (waves != 4 ? 2 : 1) * waves) * n + ((ne + 1) >> 1);
     return ((doubles * 8 + 15) / 16) * 16;
 }
 

@@ -30,6 +30,12 @@ __global__ void bench(double *out, long long *cyc, int iters, int lanesel) {
                                : "+v"(a) : "v"(tid), "s"(lanesel), "v"(tid), "v"(d) : "s20", "s21");)
         } else if (MODE == 4) {   // ds_read_b64 + ds_write_b64, conflict-free rows
             REP8(REP8({ double t = p[0]; asm volatile("" : "+v"(t)); p[64] = t; }))
+        } else if (MODE == 7) {   // ds_read_b64, every lane the same address (broadcast)
+            double *pb = lds + (tid >> 6) * 512 + (it & 7);
+            REP8(REP8({ double t = pb[0]; asm volatile("" : "+v"(t)); a += t; pb += 8; }))
+        } else if (MODE == 8) {   // ds_read_b64, one address per lane (conflict-free)
+            double *pb = lds + (tid >> 6) * 512 + (tid & 63);
+            REP8(REP8({ double t = pb[0]; asm volatile("" : "+v"(t)); a += t; pb += 1; }))
         } else if (MODE == 5) {   // v_mov_b32 (plain 32-bit VALU), dependent
             REP64(asm volatile("v_add_u32 %0, %0, %1" : "+v"(s0) : "v"(tid));)
         } else if (MODE == 6) {   // the whole row pattern: read, 2 rl, fma, write, 2 rl, fmac
@@ -46,6 +52,102 @@ __global__ void bench(double *out, long long *cyc, int iters, int lanesel) {
     const long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + tid] = a + b + c + d + s0 + s1 + p[0];
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// Replica of the block kernel's sweep: rows of `stride8` bytes, 8 loads in flight, read - fma - (write) - fmac.
+template <int STORE, int RL>
+__global__ void sweep(double *out, long long *cyc, int iters, int stride8, int rows, int lanesel, int rev, int live) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int i = tid; i < 9600; i += blockDim.x) lds[i] = 1.0 + 1e-9 * i;
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    char *col = reinterpret_cast<char *>(lds) + (rev ? (63 - lane) : lane) * 8;
+    double acc0 = 0.0, acc1 = 0.0;
+    const double w = 1e-12 * lane;
+    for (int it = 0; it < iters; ++it) if (lane <= live) {
+        double cur[8]; double *ca[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ca[u] = reinterpret_cast<double *>(col + (wave + u * nw) * stride8); cur[u] = *ca[u]; }
+        for (int g = 0; g < rows / 8; ++g) {
+            double nx[8]; double *na[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int r = wave + ((g + 1) * 8 + u) * nw; r = r < rows * nw ? r : 0;
+                na[u] = reinterpret_cast<double *>(col + r * stride8); nx[u] = *na[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                double x = 1e-3 * u;
+                if (RL) { int lo = __builtin_amdgcn_readlane(__double2loint(cur[u]), lanesel), hi = __builtin_amdgcn_readlane(__double2hiint(cur[u]), lanesel); x = __hiloint2double(hi, lo); }
+                const double nv = fma(-x, w, cur[u]);
+                if (STORE) *ca[u] = nv;
+                double xn = 1e-3 * (u + 1);
+                if (RL) { int lo = __builtin_amdgcn_readlane(__double2loint(nv), lanesel + 1), hi = __builtin_amdgcn_readlane(__double2hiint(nv), lanesel + 1); xn = __hiloint2double(hi, lo); }
+                if (u & 1) acc1 = fma(xn, nv, acc1); else acc0 = fma(xn, nv, acc0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { cur[u] = nx[u]; ca[u] = na[u]; }
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + tid] = acc0 + acc1;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int STORE, int RL>
+void run_sweep(const char *name, int stride8, int rev, int blocks_per_cu, int live = 63) {
+    double *out; long long *cyc;
+    hipMalloc(&out, 1024 * 1024 * 8); hipMalloc(&cyc, 4096 * 8);
+    const int nw = 4, rows = 32, iters = 200;
+    const size_t lds = blocks_per_cu == 2 ? 80000 : 40000;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(sweep<STORE, RL>), hipFuncAttributeMaxDynamicSharedMemorySize, 80000);
+    sweep<STORE, RL><<<256 * blocks_per_cu, 64 * nw, lds>>>(out, cyc, iters, stride8, rows, 5, rev, live);
+    hipDeviceSynchronize();
+    std::vector<long long> h(1); hipMemcpy(h.data(), cyc, 8, hipMemcpyDeviceToHost);
+    printf("%-34s live %2d stride %4d B rev %d blocks/CU %d: ticks per row per wave = %.1f\n", name, live, stride8, rev, blocks_per_cu,
+           (double)h[0] / (iters * rows));
+}
+
+// LDS throughput by lane stride: 8 independent ds_read_b64 (+ optional ds_write_b64) per iteration
+template <int WRITE>
+__global__ void lds_stride(double *out, long long *cyc, int iters, int lane_stride, int row_step) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 9800; i += blockDim.x) lds[i] = 1.0 + i;
+    __syncthreads();
+    double *p = lds + lane * lane_stride + wave;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[u * row_step];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+        if (WRITE) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u * row_step] = v[u] + 1.0;
+        }
+        a0 += v[0] + v[4]; a1 += v[1] + v[5]; a2 += v[2] + v[6]; a3 += v[3] + v[7];
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + tid] = a0 + a1 + a2 + a3;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int WRITE>
+void run_stride(int lane_stride, int row_step) {
+    double *out; long long *cyc;
+    hipMalloc(&out, 1024 * 1024 * 8); hipMalloc(&cyc, 4096 * 8);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(lds_stride<WRITE>), hipFuncAttributeMaxDynamicSharedMemorySize, 80000);
+    const int iters = 400;
+    lds_stride<WRITE><<<512, 256, 80000>>>(out, cyc, iters, lane_stride, row_step);
+    hipDeviceSynchronize();
+    std::vector<long long> h(1); hipMemcpy(h.data(), cyc, 8, hipMemcpyDeviceToHost);
+    printf("lds %s lane stride %4d doubles, row step %d: %.1f ticks per b64 access per wave (8 waves/CU) -> %.1f clk CU-wide\n",
+           WRITE ? "read+write" : "read", lane_stride, row_step, (double)h[0] / (iters * 8 * (WRITE ? 2 : 1)),
+           (double)h[0] / (iters * 8 * (WRITE ? 2 : 1)) / 8);
 }
 
 template <int MODE>
@@ -69,12 +171,25 @@ void run(const char *name, int per_iter) {
 }
 
 int main() {
+    for (int st : {1, 133, 129, 131, 135, 137, 141, 143, 145, 128, 67, 45}) run_stride<0>(st, 4);
+    for (int st : {1, 133, 129, 137}) run_stride<1>(st, 4);
+    run_sweep<1, 1>("sweep: read+write+2fma+4rl", 584, 1, 2, 61);
+    run_sweep<1, 1>("sweep: read+write+2fma+4rl", 584, 1, 2, 30);
+    for (int bpc : {2, 4}) {
+        run_sweep<0, 0>("sweep: read+2fma", 584, 1, bpc);
+        run_sweep<0, 0>("sweep: read+2fma", 512, 0, bpc);
+        run_sweep<1, 0>("sweep: read+write+2fma", 584, 1, bpc);
+        run_sweep<1, 1>("sweep: read+write+2fma+4rl", 584, 1, bpc);
+        run_sweep<1, 1>("sweep: read+write+2fma+4rl", 512, 0, bpc);
+    }
     run<0>("dp fma dependent", 64);
     run<1>("dp fma 4 chains", 256);
     run<2>("readlane x2 indep", 128);
     run<3>("rl,rl,nop,fma(sgpr)", 256);
     run<4>("ds_read+ds_write b64", 128);
     run<5>("v_add_u32 dependent", 64);
+    run<7>("ds_read_b64 broadcast + add", 128);
+    run<8>("ds_read_b64 per-lane + add", 128);
     run<6>("row pattern (9 instr)", 64 * 9);
     return 0;
 }
