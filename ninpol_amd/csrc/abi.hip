@@ -420,19 +420,32 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (c == 255) c = kGlsClasses;   // the hex8 group-kernel class
         lists[c].push_back((int32_t)targets[i]);
     }
+    // one device buffer for all class lists, filled before the first launch: a per-class allocate / copy / free
+    // cycle lets the allocator hand the same memory to the next list while the previous kernel still reads it
+    // (the pageable copy is not ordered behind that kernel)
+    std::vector<int32_t> flat;
+    std::vector<size_t> first(lists.size() + 1, 0);
+    for (size_t c = 0; c < lists.size(); ++c) {
+        first[c] = flat.size();
+        flat.insert(flat.end(), lists[c].begin(), lists[c].end());
+    }
+    first[lists.size()] = flat.size();
+    int32_t *dl0 = nullptr;
+    HIP_TRY(hipMalloc((void **)&dl0, flat.size() * 4));
+    const hipError_t cp = hipMemcpy(dl0, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
+    if (cp != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemcpy: %s", hipGetErrorString(cp)); }
     for (size_t c = 0; c < lists.size() && !rc; ++c) {
         if (lists[c].empty()) continue;
-        int32_t *dl = nullptr;
-        HIP_TRY(hipMallocAsync((void **)&dl, lists[c].size() * 4, stream));
-        HIP_TRY(hipMemcpyAsync(dl, lists[c].data(), lists[c].size() * 4, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));  // the pageable source vector dies with this scope
+        const int32_t *dl = dl0 + first[c];
         const int32_t cnt = (int32_t)lists[c].size();
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_gls_hex8(d.v, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else rc = launch_class(d, (int)c, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
-        HIP_TRY(hipFreeAsync(dl, stream));
     }
+    const hipError_t sy = hipStreamSynchronize(stream);   // the lists must outlive the kernels
+    (void)hipFree(dl0);
+    if (sy != hipSuccess) return fail(NIN_EHIP, "target kernels: %s", hipGetErrorString(sy));
     if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return NIN_OK;
 }

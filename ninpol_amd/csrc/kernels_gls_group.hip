@@ -177,6 +177,23 @@ struct NodeFetch {
 // out of the norm and of the dot products by itself.  The pivot entry alpha travels in its own slot.
 // xh = xb + h * HRP (this lane's half), xc = xb + (l16 & 1) * HRP + (l16 >> 1) (rows l16 + 16 e): every LDS
 // access is a laundered base + compile-time offset (see lds_base).
+// Publish column K (owner lanes only): x = the column BELOW the pivot, zero at the pivot and at the row above it,
+// alpha in its own slot.  LDS writes are slow to issue (~25 cycles each for one wave, tools/micro_isa.hip), so
+// column K + 1 is published from INSIDE step K, right after its own update and interleaved with the update of the
+// other columns: by the time step K + 1 reads it the data has long landed ("look-ahead" Householder).
+template <int K>
+__device__ __forceinline__ void publish(const double (&a)[Hex8::SLOTS][Hex8::HR], lds_f64 *xh, lds_f64 *xalpha, int l8, int h) {
+    constexpr int QK = K / 8, LK = K % 8, HP = K % 2, PL = K / 2, HR = Hex8::HR;
+    if (l8 == LK) {
+        const bool pivot_half = (h == HP);
+        // local row PL is the pivot row (pivot half), row K - 1 (K odd, other half) or row K + 1 (K even, other half)
+        xh[PL] = (HP == 0 && !pivot_half) ? a[QK][PL] : 0.0;
+#pragma unroll
+        for (int rl = PL + 1; rl < HR; ++rl) xh[rl] = a[QK][rl];
+        if (pivot_half) xalpha[0] = a[QK][PL];
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], double (&cr)[Hex8::CS], double (&rinv)[Hex8::SLOTS],
                                         lds_f64 *xh, const lds_f64 *xc, lds_f64 *xalpha, int l8, int h, int l16,
@@ -185,22 +202,14 @@ __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], doub
     if (K == 6) nx.level3(g);    // next pass: geometry (its ids were fetched after this pass's staging)
     if (K == 12) nx.level4(g);   // next pass: permeability and diff_mag of the faces' cells
     constexpr int QK = K / 8, LK = K % 8, HP = K % 2, PL = K / 2, RL0 = (K + 1) / 2, HR = C::HR;
+    constexpr int E0 = K / 16;                 // slots of c below E0 hold only rows above the pivot
     const bool owner = (l8 == LK);
     const bool pivot_half = (h == HP);
-    if (owner) {
-        // local row PL is the pivot row (pivot half), row K - 1 (K odd, other half) or row K + 1 (K even, other half)
-        xh[PL] = (HP == 0 && !pivot_half) ? a[QK][PL] : 0.0;
-#pragma unroll
-        for (int rl = PL + 1; rl < HR; ++rl) xh[rl] = a[QK][rl];
-        if (pivot_half) xalpha[0] = a[QK][PL];
-    }
-    lds_sync();
+    lds_sync();                                // column K was published during step K - 1 (or before the loop)
     // pass 1 over this lane's half of the published column: |x|^2 and the dot products with the lane's own
-    // columns.  The LDS pipe is shared by the 4 SIMDs of a CU and this kernel is bound by it (the publish
-    // costs ~13 LDS cycles per ds_write2_b64 whatever the exec mask), so x is read ONCE, as 16-byte
-    // ds_read_b128 where the pair is aligned, and kept in registers for pass 2.
+    // columns.  x is read ONCE, as 16-byte ds_read_b128 where the pair is aligned, and kept in registers for pass 2.
     const double alpha = xalpha[0];
-    double x[HR];
+    double x[HR], xl[C::CS];
     {
         constexpr int RA = RL0 + (RL0 & 1);          // first even local row >= RL0
         if (RL0 & 1) x[RL0] = xh[RL0];
@@ -210,6 +219,8 @@ __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], doub
             x[rl] = v.x;
             x[rl + 1] = v.y;
         }
+#pragma unroll
+        for (int e = E0; e < C::CS; ++e) xl[e] = xc[8 * e];   // the rows of c this lane holds (rows l16 + 16 e)
     }
     double ss = 0.0, d[C::SLOTS];
 #pragma unroll
@@ -243,27 +254,34 @@ __device__ __forceinline__ void qr_step(double (&a)[Hex8::SLOTS][Hex8::HR], doub
         gw[q] = w;
         a[q][PL] = fma(w, vkh, a[q][PL]);        // the pivot row (vkh = 0 elsewhere: no change)
     }
+    // pass 2.  The slot that holds column K + 1 goes first and that column is published at once; the writes drain
+    // while the other slots and the column c are updated.
+    constexpr int QN = (K + 1 < C::NA) ? (K + 1) / 8 : QK;
+#pragma unroll
+    for (int rl = RL0; rl < HR; ++rl) a[QN][rl] = fma(gw[QN], x[rl], a[QN][rl]);
+    if (K + 1 < C::NA) {
+        lds_sync();                              // every lane has read column K (x, xl, alpha) by now
+        __builtin_amdgcn_sched_barrier(0);       // keep the writes HERE: the scheduler otherwise sinks them below the
+        publish<(K + 1 < C::NA) ? K + 1 : K>(a, xh, xalpha, l8, h);   // remaining updates, back onto the critical path
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int rl = RL0; rl < HR; ++rl) {
 #pragma unroll
-        for (int q = QK; q < C::SLOTS; ++q) a[q][rl] = fma(gw[q], x[rl], a[q][rl]);
+        for (int q = QK; q < C::SLOTS; ++q)
+            if (q != QN) a[q][rl] = fma(gw[q], x[rl], a[q][rl]);
     }
     // the last column c, dealt by rows: lane l16 holds rows l16, l16 + 16, l16 + 32 (rows 44..47 are padding: 0)
     {
-        constexpr int E0 = K / 16;                 // slots below E0 hold only rows above the pivot
         const double vkc = (l16 == K % 16) ? vk : 0.0;
-        double xl[C::CS], part = vkc * cr[E0];
+        double part = vkc * cr[E0];
 #pragma unroll
-        for (int e = E0; e < C::CS; ++e) {
-            xl[e] = xc[8 * e];
-            part = fma(xl[e], cr[e], part);
-        }
+        for (int e = E0; e < C::CS; ++e) part = fma(xl[e], cr[e], part);
         const double gwc = -(gk * group16_sum(part));
         cr[E0] = fma(gwc, vkc, cr[E0]);
 #pragma unroll
         for (int e = E0; e < C::CS; ++e) cr[e] = fma(gwc, xl[e], cr[e]);
     }
-    lds_sync();                          // the next step overwrites xb
 }
 
 template <int K, int KEND>
@@ -448,8 +466,11 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) rinv[q] = 0.0;
         NIN_STAMP();
-        if (DBG != 1) QrLoop<0, NA>::run(a, cr, rinv, lds_base(xb + h * C::HRP), lds_base(xb + (l16 & 1) * C::HRP + (l16 >> 1)),
-                                         lds_base(xb + 2 * C::HRP), l8, h, l16, nx, g);
+        if (DBG != 1) {
+            lds_f64 *xh = lds_base(xb + h * C::HRP), *xalpha = lds_base(xb + 2 * C::HRP);
+            publish<0>(a, xh, xalpha, l8, h);
+            QrLoop<0, NA>::run(a, cr, rinv, xh, lds_base(xb + (l16 & 1) * C::HRP + (l16 >> 1)), xalpha, l8, h, l16, nx, g);
+        }
         if (DBG != 1 && DBG != 2) BackLoop<NA - 1>::run(a, cr, rinv, y, l8, h, l16);
         NIN_STAMP();
         if (DBG == 1 || DBG == 2) { double acc = 0; for (int q = 0; q < SLOTS; ++q) for (int rl = 0; rl < HR; ++rl) acc += a[q][rl]; y[0] = acc; }

@@ -150,6 +150,50 @@ void run_stride(int lane_stride, int row_step) {
            (double)h[0] / (iters * 8 * (WRITE ? 2 : 1)) / 8);
 }
 
+// LDS write cost by instruction flavour and exec mask: the hex8 kernel's "publish" (few active lanes)
+template <int KIND>
+__global__ void lds_write(double *out, long long *cyc, int iters, int active) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *p = lds + wave * 2048 + lane * 17;
+    const double v0 = tid, v1 = tid + 1;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    if ((lane & 7) < active) {
+        for (int it = 0; it < iters; ++it) {
+            if (KIND == 0) {   // 16 x ds_write_b64
+#pragma unroll
+                for (int u = 0; u < 16; ++u) asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"((unsigned)(size_t)p), "v"(v0), "n"(u * 8) : "memory");
+            } else if (KIND == 1) {   // 8 x ds_write2_b64
+#pragma unroll
+                for (int u = 0; u < 8; ++u) asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" :: "v"((unsigned)(size_t)p), "v"(v0), "v"(v1), "n"(2 * u), "n"(2 * u + 1) : "memory");
+            } else {   // 8 x ds_write_b128 (needs 16-byte alignment: lane * 17 doubles is odd -> use lane * 18)
+                double *q = lds + wave * 2048 + lane * 18;
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                d2 vv; vv.x = v0; vv.y = v1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"((unsigned)(size_t)q), "v"(vv), "n"(u * 16) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + tid] = lds[tid];
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int KIND>
+void run_write(const char *name, int active) {
+    double *out; long long *cyc;
+    hipMalloc(&out, 1024 * 1024 * 8); hipMalloc(&cyc, 4096 * 8);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(lds_write<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 80000);
+    const int iters = 400;
+    lds_write<KIND><<<256, 256, 80000>>>(out, cyc, iters, active);
+    hipDeviceSynchronize();
+    std::vector<long long> h(1); hipMemcpy(h.data(), cyc, 8, hipMemcpyDeviceToHost);
+    printf("ldsw %-14s active lanes %2d/64: %.1f ticks per 16 doubles per wave (4 waves/CU) -> %.2f clk per double-per-lane CU-wide\n", name,
+           active * 8, (double)h[0] / iters, (double)h[0] / iters / 16 / 4);
+}
+
 template <int MODE>
 void run(const char *name, int per_iter) {
     double *out; long long *cyc;
@@ -171,6 +215,7 @@ void run(const char *name, int per_iter) {
 }
 
 int main() {
+    for (int act : {8, 1}) { run_write<0>("ds_write_b64", act); run_write<1>("ds_write2_b64", act); run_write<2>("ds_write_b128", act); }
     for (int st : {1, 133, 129, 131, 135, 137, 141, 143, 145, 128, 67, 45}) run_stride<0>(st, 4);
     for (int st : {1, 133, 129, 137}) run_stride<1>(st, 4);
     run_sweep<1, 1>("sweep: read+write+2fma+4rl", 584, 1, 2, 61);
