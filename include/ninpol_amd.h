@@ -104,8 +104,9 @@ int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_m
  *
  * targets: int64 node ids (host pointer) or NULL for all nodes.  add_neumann != 0 applies
  * `data[j] = weights + neumann_ws[row]` of interpolator.pyx:618 in the same kernel.
- * dev_csr_data [nnz_esup] and dev_neumann_ws [n_points] are DEVICE pointers; the launch is
- * asynchronous on `stream`. */
+ * dev_csr_data [nnz_esup] and dev_neumann_ws [n_points] are DEVICE pointers; with targets == NULL the
+ * launch is asynchronous on `stream`; with a target list the call returns once the kernels have run
+ * (the device copy of the list is owned by the call). */
 int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t n_targets,
                        int add_neumann, double *dev_csr_data, double *dev_neumann_ws, void *stream);
 

@@ -573,7 +573,7 @@ int64_t nin_algorithmic_bytes(const nin_grid *g, int method) {
 const char *nin_kernel_name(int method) {
     if (method == NIN_METHOD_IDW) return "nin_rows_kernel<0>";
     if (method == NIN_METHOD_LS) return "nin_rows_kernel<1>";
-    return kernel_name_gls_hex8();   // dominant on hexahedron meshes; kernel_name_gls() covers the other nodes
+    return kernel_name_gls_hex8();   // dominant on hexahedron meshes; kernel_name_gls_block() covers the other nodes
 }
 
 }  // extern "C"
