@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--edge", dest="n", type=int, default=216, help="cells per edge per GPU (216^3 = 10,077,696)")
     ap.add_argument("--jitter", type=float, default=0.15)
     ap.add_argument("--cpu-sample", type=int, default=64, help="edge of the CPU-baseline sample mesh (0 = skip)")
+    ap.add_argument("--grid-build", default="host", choices=["host", "device"],
+                    help="where the Grid connectivity is built (north_star: host, pushed to HBM; device = SURVEY 8 f1)")
     ap.add_argument("--no-extras", action="store_true", help="skip the IDW/LS context numbers and the e2e timing")
     ap.add_argument("--check", action="store_true",
                     help="(small --edge only) rank 0 recomputes the whole mesh on its GPU and compares the gathered triplets")
@@ -126,9 +128,17 @@ def main():
     # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers; the host grid build is OpenMP code, so give
     # every rank its share of the host cores explicitly (setup only, outside the timed region)
     host_threads = max(1, (os.cpu_count() or 1) // world) if world > 1 else 0
-    I = ninpol_amd.Interpolator(device=local_rank, num_threads=host_threads)
+    I = ninpol_amd.Interpolator(device=local_rank, num_threads=host_threads, grid_build=args.grid_build)
     I.load_mesh(mesh_obj=mesh)
     t_load = time.time() - t0
+    t_load_dev = None
+    if world == 1 and not args.no_extras and args.grid_build == "host":
+        # context: the same load_mesh with the connectivity built by HIP kernels on the GPU
+        t0 = time.time()
+        I2 = ninpol_amd.Interpolator(device=local_rank, grid_build="device")
+        I2.load_mesh(mesh_obj=mesh)
+        t_load_dev = time.time() - t0
+        del I2
     del mesh
     g = I.grid
     t0 = time.time()
@@ -273,8 +283,11 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": plan.kernel_name, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": B_alg, "bytes_per_node": round(B_alg / P_loc, 1)},
-            "setup_s": {"mesh_gen": round(t_gen, 2), "load_mesh": round(t_load, 2), "push_to_hbm": round(t_push, 2)},
+            "setup_s": {"mesh_gen": round(t_gen, 2), "load_mesh": round(t_load, 2), "push_to_hbm": round(t_push, 2),
+                        "grid_build": args.grid_build},
         }
+        if t_load_dev is not None:
+            line["setup_s"]["load_mesh_with_device_grid_build"] = round(t_load_dev, 2)
         if check is not None:
             line["gather_check_bit_identical_to_single_gpu"] = check
         if rehearsal:

@@ -66,6 +66,17 @@ int nin_grid_create(int64_t dim, int64_t n_elems, int64_t n_points,
                     nin_grid **out);
 void nin_grid_destroy(nin_grid *g);
 
+/* The same Grid, built ON `device` (grid.pyx:142-231, 233-525, 669-809 as data-parallel HIP kernels,
+ * csrc/grid_device.hip): same arguments, same arrays bit for bit.  The arrays the weight kernels read stay in
+ * HBM -- a later nin_grid_to_device(g, device) adopts them instead of uploading -- and all of them are mirrored
+ * to the host for nin_grid_array_*.  No CPU fallback: NIN_ENODEVICE without a GPU. */
+int nin_grid_create_on_device(int64_t dim, int64_t n_elems, int64_t n_points,
+                              const int64_t *npoel, const int64_t *nfael, const int64_t *lnofa,
+                              const int64_t *lpofa, const int64_t *nedel, const int64_t *lpoed,
+                              const int64_t *connectivity, const int64_t *element_types,
+                              const double *coords, int coords_dim, int build_edges, int device,
+                              nin_grid **out);
+
 /* Readonly attributes of Grid (grid.pxd:128-187).  Scalars: dim n_elems n_points n_faces n_edges
  * MX_ELEMENTS_PER_POINT MX_POINTS_PER_POINT MX_ELEMENTS_PER_FACE MX_FACES_PER_POINT.  Unknown -> -1. */
 int64_t nin_grid_scalar(const nin_grid *g, const char *name);

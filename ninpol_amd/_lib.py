@@ -14,7 +14,7 @@ NIN_EINVAL, NIN_ENOMEM, NIN_EHIP, NIN_ENODEVICE, NIN_ERANGE, NIN_ESTATE = -1, -2
 METHOD_ID = {"gls": 0, "idw": 1, "ls": 2}
 
 EXPORTS = (
-    "nin_last_error", "nin_version", "nin_grid_create", "nin_grid_destroy", "nin_grid_scalar",
+    "nin_last_error", "nin_version", "nin_grid_create", "nin_grid_create_on_device", "nin_grid_destroy", "nin_grid_scalar",
     "nin_grid_array_info", "nin_grid_array_copy", "nin_device_count", "nin_grid_to_device", "nin_grid_device",
     "nin_fields_set", "nin_weights_device", "nin_weights_host", "nin_csr_compact_host", "nin_interpolate_csr_host", "nin_apply_host",
     "nin_algorithmic_bytes", "nin_kernel_name",
@@ -42,6 +42,7 @@ def load():
     L.nin_last_error.restype = cp
     L.nin_version.restype = cp
     L.nin_grid_create.argtypes = [i64, i64, i64] + [vp] * 9 + [i32, i32, i32, ctypes.POINTER(vp)]
+    L.nin_grid_create_on_device.argtypes = [i64, i64, i64] + [vp] * 9 + [i32, i32, i32, ctypes.POINTER(vp)]
     L.nin_grid_destroy.argtypes = [vp]
     L.nin_grid_destroy.restype = None
     L.nin_grid_scalar.argtypes = [vp, cp]

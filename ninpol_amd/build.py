@@ -25,6 +25,8 @@ UNITS = [
     ("kernels_gls_block.hip", "hipcc", []),
     ("kernels_gls_group.hip", "hipcc", []),
     ("kernels_csr.hip", "hipcc", []),
+    # device-side grid build: no contraction, like grid_host.cpp (float32 normals must match the reference)
+    ("grid_device.hip", "hipcc", ["-ffp-contract=off"]),
     ("abi.hip", "hipcc", ["-Wno-unknown-pragmas"]),
 ]
 

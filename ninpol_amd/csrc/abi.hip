@@ -72,11 +72,6 @@ void dev_free_all(DeviceGrid &d) {
     d = DeviceGrid{};
 }
 
-// LDS bytes a node's system may take in class c and the waves per node the block kernel runs it with
-// (16 / 5 / 2 / 1 workgroups per CU); the last class keeps its systems in global-memory scratch.
-const int32_t kClassBudget[kGlsClasses] = {10240, 32768, 81920, 159744, 0};
-const int32_t kClassWaves[kGlsClasses] = {1, 2, 4, 8, 1};
-
 struct ArrayRef {
     int dtype;      // NIN_I64 / NIN_F64
     int64_t count;
@@ -84,8 +79,30 @@ struct ArrayRef {
     const void *ptr;
 };
 
+unsigned array_bits(const std::string &name) {
+    if (name == "esup") return A_ESUP;
+    if (name == "esup_ptr") return A_ESUP_PTR;
+    if (name == "fsup") return A_FSUP;
+    if (name == "fsup_ptr") return A_FSUP_PTR;
+    if (name == "esuf" || name == "esuf_ptr") return A_ESUF;
+    if (name == "esuel") return A_ESUEL;
+    if (name == "infael") return A_INFAEL;
+    if (name == "inpofa") return A_INPOFA;
+    if (name == "inpoel") return A_INPOEL;
+    if (name == "boundary_faces") return A_BFACES;
+    if (name == "boundary_points") return A_BPOINTS;
+    if (name == "element_types") return A_ETYPE;
+    if (name == "point_coords") return A_COORDS;
+    if (name == "centroids") return A_CENTROIDS;
+    if (name == "faces_centers") return A_FCENTERS;
+    if (name == "faces_areas") return A_AREAS;
+    if (name == "normal_faces") return A_NORMALS;
+    return 0;   // psup / edges: their builders ask for what they read
+}
+
 bool lookup_array(nin_grid *g, const std::string &name, ArrayRef *r) {
     HostGrid &h = g->h;
+    if (h.ensure(array_bits(name))) return false;   // a grid built on the device: bring the array over first
     auto I32 = [&](const std::vector<int32_t> &v) { *r = {NIN_I64, (int64_t)v.size(), 0, v.data()}; return true; };
     auto I64 = [&](const std::vector<int64_t> &v) { *r = {NIN_I64, (int64_t)v.size(), 1, v.data()}; return true; };
     auto U8 = [&](const std::vector<uint8_t> &v) { *r = {NIN_I64, (int64_t)v.size(), 2, v.data()}; return true; };
@@ -127,10 +144,10 @@ extern "C" {
 const char *nin_last_error(void) { return g_err.c_str(); }
 const char *nin_version(void) { return "ninpol_amd 0.1 (gfx950)"; }
 
-int nin_grid_create(int64_t dim, int64_t n_elems, int64_t n_points, const int64_t *npoel, const int64_t *nfael,
-                    const int64_t *lnofa, const int64_t *lpofa, const int64_t *nedel, const int64_t *lpoed,
-                    const int64_t *connectivity, const int64_t *element_types, const double *coords, int coords_dim,
-                    int build_edges, int num_threads, nin_grid **out) {
+static int grid_create_common(int64_t dim, int64_t n_elems, int64_t n_points, const int64_t *npoel, const int64_t *nfael,
+                              const int64_t *lnofa, const int64_t *lpofa, const int64_t *nedel, const int64_t *lpoed,
+                              const int64_t *connectivity, const int64_t *element_types, const double *coords,
+                              int coords_dim, int build_edges, int num_threads, int device, nin_grid **out) {
     if (!out) return fail(NIN_EINVAL, "out is NULL");
     *out = nullptr;
     // the three checks of grid.pyx:55-60 (the Python layer turns them into the reference's ValueErrors)
@@ -141,6 +158,12 @@ int nin_grid_create(int64_t dim, int64_t n_elems, int64_t n_points, const int64_
         return fail(NIN_EINVAL, "NULL table or array");
     if (coords_dim < 1 || coords_dim > 3) return fail(NIN_EINVAL, "coords_dim must be 1..3");
     if (n_elems * 8 >= INT32_MAX || n_points >= INT32_MAX) return fail(NIN_ERANGE, "mesh too large for the int32 layout");
+    if (device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            return fail(NIN_ENODEVICE, "no HIP device visible: the device grid build has no CPU fallback (use nin_grid_create)");
+        if (device >= ndev) return fail(NIN_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    }
     nin_grid *g = new (std::nothrow) nin_grid();
     if (!g) return fail(NIN_ENOMEM, "out of host memory");
     HostGrid &h = g->h;
@@ -158,16 +181,39 @@ int nin_grid_create(int64_t dim, int64_t n_elems, int64_t n_points, const int64_
             for (int k = 0; k < 2; ++k) h.lpoed[t][e][k] = (int32_t)lpoed[(t * kMaxEdgesPerElement + e) * 2 + k];
     }
     int rc;
+    std::string err;
     try {
-        rc = h.build(connectivity, element_types, coords, coords_dim);
+        if (device >= 0) rc = build_grid_on_device(h, g->d, device, connectivity, element_types, coords, coords_dim, &err);
+        else rc = h.build(connectivity, element_types, coords, coords_dim);
     } catch (const std::bad_alloc &) {
+        dev_free_all(g->d);
         delete g;
         return fail(NIN_ENOMEM, "out of host memory while building the grid");
     }
-    if (rc == -5) { delete g; return fail(NIN_ERANGE, "a connectivity count does not fit int32"); }
-    if (rc) { delete g; return fail(NIN_EINVAL, "connectivity references a point outside [0, n_points) or an unknown element type"); }
+    if (rc) { dev_free_all(g->d); delete g; }
+    if (rc == -5) return fail(NIN_ERANGE, "a connectivity count does not fit int32");
+    if (rc == -2) return fail(NIN_ENOMEM, "device grid build: %s", err.c_str());
+    if (rc == -3) return fail(NIN_EHIP, "device grid build: %s", err.c_str());
+    if (rc) return fail(NIN_EINVAL, "connectivity references a point outside [0, n_points) or an unknown element type");
     *out = g;
     return NIN_OK;
+}
+
+int nin_grid_create(int64_t dim, int64_t n_elems, int64_t n_points, const int64_t *npoel, const int64_t *nfael,
+                    const int64_t *lnofa, const int64_t *lpofa, const int64_t *nedel, const int64_t *lpoed,
+                    const int64_t *connectivity, const int64_t *element_types, const double *coords, int coords_dim,
+                    int build_edges, int num_threads, nin_grid **out) {
+    return grid_create_common(dim, n_elems, n_points, npoel, nfael, lnofa, lpofa, nedel, lpoed, connectivity, element_types,
+                              coords, coords_dim, build_edges, num_threads, -1, out);
+}
+
+int nin_grid_create_on_device(int64_t dim, int64_t n_elems, int64_t n_points, const int64_t *npoel, const int64_t *nfael,
+                              const int64_t *lnofa, const int64_t *lpofa, const int64_t *nedel, const int64_t *lpoed,
+                              const int64_t *connectivity, const int64_t *element_types, const double *coords,
+                              int coords_dim, int build_edges, int device, nin_grid **out) {
+    if (device < 0) return fail(NIN_EINVAL, "device must be >= 0");
+    return grid_create_common(dim, n_elems, n_points, npoel, nfael, lnofa, lpofa, nedel, lpoed, connectivity, element_types,
+                              coords, coords_dim, build_edges, 0, device, out);
 }
 
 void nin_grid_destroy(nin_grid *g) {
@@ -190,8 +236,8 @@ int64_t nin_grid_scalar(const nin_grid *g, const char *name) {
     if (n == "MX_ELEMENTS_PER_FACE") return h.mx_elems_per_face;
     if (n == "MX_FACES_PER_POINT") return h.mx_faces_per_point;
     if (n == "coords_dim") return g->coords_dim;
-    if (n == "nnz_esup") return (int64_t)h.esup.size();
-    if (n == "nnz_fsup") return (int64_t)h.fsup.size();
+    if (n == "nnz_esup") return h.nnz_esup;
+    if (n == "nnz_fsup") return h.nnz_fsup;
     return -1;
 }
 
@@ -232,7 +278,8 @@ int nin_device_count(int *count) {
     return NIN_OK;
 }
 
-int nin_grid_device(const nin_grid *g) { return g ? g->d.device : -1; }
+// a grid built on the device holds its arrays there but has no launch plan yet: not "on the device" until to_device
+int nin_grid_device(const nin_grid *g) { return (g && !g->d.prebuilt) ? g->d.device : -1; }
 
 int nin_grid_to_device(nin_grid *g, int device) {
     if (!g) return fail(NIN_EINVAL, "NULL grid");
@@ -240,17 +287,24 @@ int nin_grid_to_device(nin_grid *g, int device) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(NIN_ENODEVICE, "no HIP device visible: libninpol_amd has no CPU fallback for the weight kernels");
     if (device < 0 || device >= ndev) return fail(NIN_EINVAL, "device %d out of range (%d visible)", device, ndev);
-    dev_free_all(g->d);
-    HIP_TRY(hipSetDevice(device));
+    const bool adopt = g->d.prebuilt && g->d.device == device;   // built on this device: the arrays are already there
     HostGrid &h = g->h;
+    if (!adopt) {
+        std::string err;   // a device-built grid moving elsewhere: everything comes to the host before its HBM copy goes
+        if (h.ensure(A_ALL, &err)) return fail(NIN_EHIP, "mirroring the device-built grid: %s", err.c_str());
+        dev_free_all(g->d);
+    }
+    HIP_TRY(hipSetDevice(device));
     DeviceGrid &d = g->d;
     d.device = device;
+    d.prebuilt = false;
     const int64_t P = h.n_points, E = h.n_elems, F = h.n_faces;
-    d.nnz_e = (int64_t)h.esup.size();
-    d.nnz_f = (int64_t)h.fsup.size();
+    d.nnz_e = h.nnz_esup;
+    d.nnz_f = h.nnz_fsup;
     GridView &v = d.v;
     v.n_points = (int32_t)P; v.n_elems = (int32_t)E; v.n_faces = (int32_t)F; v.dim = (int32_t)h.dim;
     int rc;
+    if (!adopt) {
     {
         std::vector<int32_t> p32((size_t)P + 1);
         for (int64_t i = 0; i <= P; ++i) p32[i] = (int32_t)h.esup_ptr[i];
@@ -274,9 +328,11 @@ int nin_grid_to_device(nin_grid *g, int device) {
         }
         if ((rc = dev_upload(d, &v.face_cells, fc))) return rc;
     }
+    }
     {   // flags start as "boundary only"; nin_fields_set adds the Neumann bit
         uint8_t *fl = nullptr;
         if ((rc = dev_alloc(d, &fl, (size_t)P))) return rc;
+        if (h.ensure(A_BPOINTS)) return fail(NIN_EHIP, "mirroring boundary_points failed");
         HIP_TRY(hipMemcpy(fl, h.boundary_points.data(), (size_t)P, hipMemcpyHostToDevice));
         v.flags = fl;
         double *perm = nullptr, *dm = nullptr;
@@ -284,34 +340,33 @@ int nin_grid_to_device(nin_grid *g, int device) {
         if ((rc = dev_alloc(d, &dm, (size_t)E))) return rc;
         v.perm = perm; v.diff_mag = dm;
     }
-    // ---- GLS launch plan: bin nodes by the size of their least-squares system -----------------------
+    // ---- GLS launch plan: bin nodes by the size of their least-squares system (classified on the device) ----
     g->node_class.assign((size_t)P, 0);
     std::vector<std::vector<int32_t>> lists(kGlsClasses);
     std::vector<int32_t> hex8_list;
     const bool use_group = getenv("NIN_GLS_NO_GROUP") == nullptr;   // debugging switch: force the generic kernel
     const bool force_global = getenv("NIN_GLS_FORCE_GLOBAL") != nullptr;   // testing switch: systems in global scratch
     int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0}, cols_max[kGlsClasses] = {0};
+    {
+        uint8_t *dcls = nullptr;
+        unsigned long long *dmax = nullptr, hmax[3 * kGlsClasses];
+        HIP_TRY(hipMalloc((void **)&dcls, (size_t)P));
+        if (hipMalloc((void **)&dmax, sizeof hmax) != hipSuccess) { (void)hipFree(dcls); return fail(NIN_ENOMEM, "hipMalloc"); }
+        hipError_t e1 = hipMemset(dmax, 0, sizeof hmax);
+        const int lrc = launch_classify(d.v, use_group, force_global, dcls, dmax, nullptr);
+        if (e1 == hipSuccess) e1 = hipMemcpy(g->node_class.data(), dcls, (size_t)P, hipMemcpyDeviceToHost);
+        if (e1 == hipSuccess) e1 = hipMemcpy(hmax, dmax, sizeof hmax, hipMemcpyDeviceToHost);
+        (void)hipFree(dcls);
+        (void)hipFree(dmax);
+        if (lrc || e1 != hipSuccess) return fail(NIN_EHIP, "node classification: %s", hipGetErrorString(e1));
+        for (int c = 0; c < kGlsClasses; ++c) {
+            need_max[c] = (int64_t)hmax[3 * c]; rows_max[c] = (int64_t)hmax[3 * c + 1]; cols_max[c] = (int64_t)hmax[3 * c + 2];
+        }
+    }
     for (int64_t p = 0; p < P; ++p) {
-        const int64_t ne = h.esup_ptr[p + 1] - h.esup_ptr[p], nf = h.fsup_ptr[p + 1] - h.fsup_ptr[p];
-        int64_t nbf = 0;
-        for (int64_t q = h.fsup_ptr[p]; q < h.fsup_ptr[p + 1]; ++q) nbf += h.boundary_faces[h.fsup[q]];
-        if (use_group && ne == 8 && nf == 12 && nbf == 0 && h.dim == 3) {
-            g->node_class[p] = 255;
-            hex8_list.push_back((int32_t)p);
-            continue;
-        }
-        const int64_t m = ne + 3 * (nf - nbf) + nbf, n = 3 * ne + 1;
-        int c = kGlsClasses - 1;
-        int64_t bytes = ((((ne + 1) >> 1) + n + m * n) * 8 + 15) / 16 * 16;   // the scratch slot of the wave kernel
-        for (int k = 0; k < kGlsClasses - 1 && !force_global && n <= 256; ++k) {
-            const int64_t need = gls_block_lds_bytes(ne, m, n, kClassWaves[k]);
-            if (need <= kClassBudget[k]) { c = k; bytes = need; break; }
-        }
-        g->node_class[p] = (uint8_t)c;
-        lists[c].push_back((int32_t)p);
-        need_max[c] = std::max(need_max[c], bytes);
-        rows_max[c] = std::max(rows_max[c], m);
-        cols_max[c] = std::max(cols_max[c], n);
+        const uint8_t c = g->node_class[p];
+        if (c == 255) hex8_list.push_back((int32_t)p);
+        else lists[c].push_back((int32_t)p);
     }
     for (int c = 0; c < kGlsClasses; ++c) {
         auto &k = d.gls[c];
@@ -320,7 +375,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         k.rows_per_lane = (int32_t)std::max<int64_t>(1, (rows_max[c] + 63) / 64);
         k.max_rows = (int32_t)rows_max[c];
         k.max_cols = (int32_t)cols_max[c];
-        k.waves = kClassWaves[c];
+        k.waves = gls_class_waves(c);
         k.col_slots = (int32_t)std::max<int64_t>(1, (cols_max[c] + 63) / 64);
         const int32_t *lp = nullptr;
         if (k.count && (rc = dev_upload(d, &lp, lists[c]))) return rc;
@@ -349,7 +404,8 @@ int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_m
                    const double *neumann_val) {
     (void)neumann_val;  // only feeds the Neumann RHS column, which gls.pyx:464-472 never reads back
     if (!g) return fail(NIN_EINVAL, "NULL grid");
-    if (g->d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
+    if (g->d.device < 0 || g->d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
+    if (g->h.ensure(A_BPOINTS)) return fail(NIN_EHIP, "mirroring boundary_points failed");
     if (!neumann_flag) return fail(NIN_EINVAL, "neumann_flag is required by every method");
     HIP_TRY(hipSetDevice(g->d.device));
     HostGrid &h = g->h;
@@ -385,7 +441,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
                        double *dev_csr_data, double *dev_neumann_ws, void *stream_) {
     if (!g || !dev_csr_data || !dev_neumann_ws) return fail(NIN_EINVAL, "NULL argument");
     DeviceGrid &d = g->d;
-    if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
+    if (d.device < 0 || d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
     if (!d.fields_set) return fail(NIN_ESTATE, "nin_fields_set has not been called");
     if (method != NIN_METHOD_GLS && method != NIN_METHOD_IDW && method != NIN_METHOD_LS)
         return fail(NIN_EINVAL, "unknown method %d", method);
@@ -564,7 +620,7 @@ int64_t nin_algorithmic_bytes(const nin_grid *g, int method) {
     //   B_idw/ls = 4(P+1) + 4 nnz_esup + 24P + 24E + 2P + (8+4) nnz_out + 8P          (nnz_out = nnz_esup)
     //   B_gls    = B_idw/ls + 4(P+1) + 4 nnz_fsup + F (2*4 + 1 + 24 + 24) + E (72+8) + 8P
     const int64_t P = g->h.n_points, E = g->h.n_elems, F = g->h.n_faces;
-    const int64_t nze = (int64_t)g->h.esup.size(), nzf = (int64_t)g->h.fsup.size();
+    const int64_t nze = g->h.nnz_esup, nzf = g->h.nnz_fsup;
     int64_t b = 4 * (P + 1) + 4 * nze + 24 * P + 24 * E + 2 * P + 12 * nze + 8 * P;
     if (method == NIN_METHOD_GLS) b += 4 * (P + 1) + 4 * nzf + F * 57 + E * 80 + 8 * P;
     return b;

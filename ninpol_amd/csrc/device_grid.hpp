@@ -6,6 +6,7 @@
 // values they are.  Everything is structure-of-arrays; rows of esup / fsup are contiguous.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace nin {
@@ -26,13 +27,43 @@ struct GridView {  // passed to kernels by value
     const uint8_t *flags;      // [P]       bit0 boundary_points, bit1 neumann flag
 };
 
+#ifdef __HIPCC__
+#define NIN_HD __host__ __device__
+#else
+#define NIN_HD
+#endif
+
 constexpr int kGlsClasses = 5;  // four LDS budget classes (1 / 2 / 4 / 8 waves per node) + one global-scratch class
+// LDS bytes a node's system may take in class c and the waves per node the block kernel runs it with
+// (16 / 5 / 2 / 1 workgroups per CU); the last class keeps its systems in global-memory scratch.
+NIN_HD inline int32_t gls_class_budget(int c) { return c == 0 ? 10240 : c == 1 ? 32768 : c == 2 ? 81920 : c == 3 ? 159744 : 0; }
+NIN_HD inline int32_t gls_class_waves(int c) { return c == 0 ? 1 : c == 1 ? 2 : c == 2 ? 4 : c == 3 ? 8 : 1; }
+// LDS bytes of one node's system in the block kernel (kernels_gls_block.hip): (n + 1) columns of odd pitch m | 1,
+// the partial-dot buffers (later y and the weight row) and the staged cell ids
+NIN_HD inline int64_t gls_block_lds_bytes(int64_t ne, int64_t m, int64_t n, int waves) {
+    const int64_t doubles = (n + 1) * (m | 1) + (waves == 1 ? 2 : (waves != 4 ? 2 : 1) * waves) * n + ((ne + 1) >> 1);
+    return ((doubles * 8 + 15) / 16) * 16;
+}
+// Size class of a node with ne cells, nf faces of which nbf on the boundary; *bytes = what it needs there.
+NIN_HD inline int gls_node_class(int64_t ne, int64_t nf, int64_t nbf, bool force_global, int64_t *bytes, int64_t *rows,
+                                 int64_t *cols) {
+    const int64_t m = ne + 3 * (nf - nbf) + nbf, n = 3 * ne + 1;
+    int c = kGlsClasses - 1;
+    int64_t b = ((((ne + 1) >> 1) + n + m * n) * 8 + 15) / 16 * 16;   // the scratch slot of the wave kernel
+    for (int k = 0; k < kGlsClasses - 1 && !force_global && n <= 256; ++k) {
+        const int64_t need = gls_block_lds_bytes(ne, m, n, gls_class_waves(k));
+        if (need <= gls_class_budget(k)) { c = k; b = need; break; }
+    }
+    *bytes = b; *rows = m; *cols = n;
+    return c;
+}
 
 struct DeviceGrid {
     int device = -1;
     GridView v{};
     int64_t nnz_e = 0, nnz_f = 0;
     bool fields_set = false, have_perm = false;
+    bool prebuilt = false;  // arrays came from build_grid_on_device(): nin_grid_to_device adopts them, no upload
     std::vector<void *> allocs;  // everything hipMalloc'd, freed together
 
     // GLS launch plan: nodes binned by the LDS bytes their least-squares system needs
@@ -50,5 +81,11 @@ struct DeviceGrid {
     int64_t gls_scratch_stride = 0; // doubles per wave slot
     int32_t gls_scratch_slots = 0;
 };
+
+struct HostGrid;
+// grid_device.hip: connectivity + geometry built on `device`, left in `d` and mirrored into `h`.
+// 0, -1 bad connectivity, -2 memory, -3 HIP (text in *err), -5 a count does not fit int32.
+int build_grid_on_device(HostGrid &h, DeviceGrid &d, int device, const int64_t *connectivity,
+                         const int64_t *element_types, const double *xyz, int coords_dim, std::string *err);
 
 }  // namespace nin

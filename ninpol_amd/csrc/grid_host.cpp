@@ -329,13 +329,36 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
         }
     }
     lap("geometry");
+    nnz_esup = (int64_t)esup.size();
+    nnz_fsup = (int64_t)fsup.size();
     if (build_edges) build_inedel();
     return 0;
+}
+
+void HostGrid::widen(const std::vector<int32_t> &src, std::vector<int64_t> &dst) {
+    const int64_t n = (int64_t)src.size();
+    dst.resize(src.size());
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) dst[i] = src[i];
+}
+
+void HostGrid::esuf_from_pairs(const std::vector<int32_t> &pairs) {
+    const int64_t F = (int64_t)pairs.size() / 2;
+    esuf_ptr.resize((size_t)F + 1);
+    esuf_ptr[0] = 0;
+    for (int64_t f = 0; f < F; ++f) esuf_ptr[f + 1] = esuf_ptr[f] + (pairs[2 * f + 1] == -1 ? 1 : 2);
+    esuf.resize((size_t)esuf_ptr[F]);
+#pragma omp parallel for schedule(static)
+    for (int64_t f = 0; f < F; ++f) {
+        esuf[esuf_ptr[f]] = pairs[2 * f];
+        if (pairs[2 * f + 1] != -1) esuf[esuf_ptr[f] + 1] = pairs[2 * f + 1];
+    }
 }
 
 // grid.pyx:269-302: unique neighbour points in order of first encounter (per point independent).
 void HostGrid::build_psup() {
     if (psup_built) return;
+    ensure(A_INPOEL | A_ETYPE | A_ESUP_PTR | A_ESUP);
     const int64_t P = n_points;
     psup_ptr.assign((size_t)P + 1, 0);
     auto gather = [&](int64_t p, std::vector<int32_t> &buf) {
@@ -379,6 +402,7 @@ void HostGrid::build_psup() {
 // That is the contract, so the same hash and the same truncation are used here.
 void HostGrid::build_inedel() {
     if (edges_built) return;
+    ensure(A_INPOEL | A_ETYPE);
     const int64_t E = n_elems;
     inedel.assign((size_t)E * kMaxEdgesPerElement, -1);
     inpoed.clear();

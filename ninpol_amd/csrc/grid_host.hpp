@@ -1,6 +1,7 @@
 // grid_host.hpp -- host-side Grid of libninpol_amd (internal; the public surface is include/ninpol_amd.h)
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -13,6 +14,19 @@ constexpr int kNumElementTypes = 8;      // :5
 constexpr int kMaxEdgesPerElement = 12;  // :6
 
 struct DeviceGrid;  // device mirror, defined in device_grid.hpp
+
+// the arrays of a HostGrid, as bits: a grid built on the device brings them to the host on first use
+enum : unsigned {
+    A_INPOEL = 1u << 0, A_ETYPE = 1u << 1, A_ESUP_PTR = 1u << 2, A_ESUP = 1u << 3, A_FSUP_PTR = 1u << 4, A_FSUP = 1u << 5,
+    A_ESUF = 1u << 6, A_ESUEL = 1u << 7, A_INFAEL = 1u << 8, A_INPOFA = 1u << 9, A_BFACES = 1u << 10, A_BPOINTS = 1u << 11,
+    A_COORDS = 1u << 12, A_CENTROIDS = 1u << 13, A_FCENTERS = 1u << 14, A_NORMALS = 1u << 15, A_AREAS = 1u << 16,
+    A_ALL = (1u << 17) - 1
+};
+struct HostGrid;
+struct LazyArrays {   // implemented by the device builder (grid_device.hip)
+    virtual ~LazyArrays() {}
+    virtual int fetch(HostGrid &h, unsigned which, std::string *err) = 0;   // 0 or a negative code
+};
 
 struct HostGrid {
     int64_t dim = 0, n_elems = 0, n_points = 0, n_faces = 0, n_edges = 0;
@@ -54,7 +68,24 @@ struct HostGrid {
 
     DeviceGrid *dev = nullptr;
 
+    // arrays present on the host (everything, unless the grid was built on the device)
+    unsigned have = A_ALL;
+    std::unique_ptr<LazyArrays> lazy;
+    int64_t nnz_esup = 0, nnz_fsup = 0;
+    int ensure(unsigned which, std::string *err = nullptr) {
+        const unsigned need = which & ~have;
+        if (!need || !lazy) return 0;
+        std::string local;
+        const int rc = lazy->fetch(*this, need, err ? err : &local);
+        if (!rc) have |= need;
+        if (have == A_ALL) lazy.reset();
+        return rc;
+    }
+
     int build(const int64_t *connectivity, const int64_t *element_types, const double *xyz, int coords_dim);
+    // used by the device builder (grid_device.hip) when it mirrors its int32 arrays into this object
+    static void widen(const std::vector<int32_t> &src, std::vector<int64_t> &dst);
+    void esuf_from_pairs(const std::vector<int32_t> &pairs);   // [F][2] (creator, neighbour or -1) -> esuf_ptr, esuf
     void build_psup();
     void build_inedel();
 };

@@ -520,11 +520,6 @@ int launch_block_cs(int cs, const GridView &g, const int32_t *nodes, int32_t cou
 
 }  // namespace
 
-int64_t gls_block_lds_bytes(int64_t ne, int64_t m, int64_t n, int waves) {
-    const int64_t doubles = (n + 1) * (m | 1) + (waves == 1 ? 2 : (waves != 4 ? 2 : 1) * waves) * n + ((ne + 1) >> 1);
-    return ((doubles * 8 + 15) / 16) * 16;
-}
-
 int launch_gls_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t waves, int32_t col_slots,
                      int32_t lds_bytes, int add_neumann, double *out, double *nws, hipStream_t stream) {
     if (count <= 0) return 0;

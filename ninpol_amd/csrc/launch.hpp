@@ -19,7 +19,6 @@ int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int
                      int32_t rows_per_lane, int add_neumann, double *out, double *nws,
                      double *scratch, int64_t scratch_stride, int32_t scratch_slots, hipStream_t stream);
 // the block kernel (kernels_gls_block.hip): one node per workgroup of `waves` wavefronts, system in LDS
-int64_t gls_block_lds_bytes(int64_t ne, int64_t m, int64_t n, int waves);
 int launch_gls_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t waves, int32_t col_slots,
                      int32_t lds_bytes, int add_neumann, double *out, double *nws, hipStream_t stream);
 const char *kernel_name_gls_block();
@@ -35,6 +34,11 @@ int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr
                    double *vals, hipStream_t stream);
 
 int launch_apply(const GridView &g, const double *data, const double *u, double *values, hipStream_t stream);
+
+// GLS launch plan (grid_device.hip): size class of every node (255 = the hex8 group kernel) and, per class, the
+// maxima of (bytes, rows, columns) as 3 * kGlsClasses unsigned 64-bit values; all DEVICE pointers
+int launch_classify(const GridView &g, int use_group, int force_global, uint8_t *node_class,
+                    unsigned long long *class_max, hipStream_t stream);
 
 const char *kernel_name_idw();
 const char *kernel_name_ls();

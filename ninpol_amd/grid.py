@@ -35,7 +35,7 @@ class Grid:
     """
 
     def __init__(self, dim, n_elems, n_points, npoel, nfael, lnofa, lpofa, nedel, lpoed, connectivity,
-                 element_types, logging=False, build_edges=False, coords=None, num_threads=0):
+                 element_types, logging=False, build_edges=False, coords=None, num_threads=0, build_device=None):
         # grid.pyx:55-60
         if dim < 1:
             raise ValueError("The number of dimensions must be greater than 0.")
@@ -66,9 +66,14 @@ class Grid:
         self._cache = {}
         self._h = ctypes.c_void_p()
         L = _lib.load()
-        rc = L.nin_grid_create(int(dim), int(n_elems), int(n_points), *[_ptr(a) for a in tabs], _ptr(conn),
-                               _ptr(etypes), _ptr(xyz), int(xyz.shape[1]), int(bool(build_edges)),
-                               int(num_threads), ctypes.byref(self._h))
+        if build_device is None:   # the native OpenMP builder (csrc/grid_host.cpp)
+            rc = L.nin_grid_create(int(dim), int(n_elems), int(n_points), *[_ptr(a) for a in tabs], _ptr(conn),
+                                   _ptr(etypes), _ptr(xyz), int(xyz.shape[1]), int(bool(build_edges)),
+                                   int(num_threads), ctypes.byref(self._h))
+        else:                      # the same arrays built by HIP kernels on that GPU (csrc/grid_device.hip)
+            rc = L.nin_grid_create_on_device(int(dim), int(n_elems), int(n_points), *[_ptr(a) for a in tabs], _ptr(conn),
+                                             _ptr(etypes), _ptr(xyz), int(xyz.shape[1]), int(bool(build_edges)),
+                                             int(build_device), ctypes.byref(self._h))
         if rc == _lib.NIN_EINVAL:
             raise ValueError(L.nin_last_error().decode())
         _lib.check(rc)

@@ -92,8 +92,15 @@ def _run_weights(grid, method, cells_data, points_data, variable_to_index, varia
 
 
 class Interpolator:
-    def __init__(self, name="interpolator", logging=False, build_edges=False, device=0, num_threads=0):
+    def __init__(self, name="interpolator", logging=False, build_edges=False, device=0, num_threads=0,
+                 grid_build="host"):
+        """Extra keywords next to the reference's: `device` (which GPU), `num_threads` (OpenMP threads of the host
+        grid builder), `grid_build` = "host" (north_star: connectivity built on the host and pushed to HBM) or
+        "device" (the same arrays built by HIP kernels on `device`, csrc/grid_device.hip)."""
         _lib.load()   # fail here, loudly, if the native library is missing
+        if grid_build not in ("host", "device"):
+            raise ValueError("grid_build must be 'host' or 'device'")
+        self.grid_build = grid_build
         self.name = name
         self.point_ordering = T.POINT_ORDERING           # utils/point_ordering.yaml as data
         self.is_grid_initialized = False
@@ -140,7 +147,8 @@ class Interpolator:
         t0 = time.time()
         args = self.process_mesh(self.mesh_obj)
         self.points_coords = np.ascontiguousarray(np.asarray(self.mesh_obj.points).astype(DTYPE_F))
-        self.grid = Grid(*args, coords=self.points_coords, num_threads=self.num_threads)
+        self.grid = Grid(*args, coords=self.points_coords, num_threads=self.num_threads,
+                         build_device=self.device if self.grid_build == "device" else None)
         self._log(f"Grid built in {time.time() - t0:.2f} seconds")
         t0 = time.time()
         self.variable_to_index = {"points": {}, "cells": {}, "faces": {}}
@@ -225,10 +233,11 @@ class Interpolator:
         module is built with cdivision=True (setup.py:100-108), so the exponent is 0 and the value the
         reference uses is (1 - 3 / tr K)^2.  Only this form reproduces the GLS numbers the reference
         publishes (tests/test_kat.py)."""
-        Ks = np.reshape(np.asarray(permeability, dtype=DTYPE_F), (len(permeability), 3, 3))
-        det = np.linalg.det(Ks)
-        tr = np.trace(Ks, axis1=1, axis2=2)
-        return (1 - (3 * (det ** 0) / tr)) ** 2
+        K = np.reshape(np.asarray(permeability, dtype=DTYPE_F), (len(permeability), 9))
+        tr = (K[:, 0] + K[:, 4]) + K[:, 8]           # np.trace's order
+        # det ** 0 == 1.0 for every float (0, inf and nan included), so the determinant is not computed:
+        # 3 * 1.0 / tr is the value the reference's expression yields, bit for bit
+        return (1 - (3 * 1.0 / tr)) ** 2
 
     def load_face_data(self, data_dict, face_connectivity=np.array([[]], dtype=int)):
         """interpolator.pyx:456-499."""
