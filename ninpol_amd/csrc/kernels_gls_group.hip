@@ -356,19 +356,34 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
     int n_stamp = 0;
 #define NIN_STAMP() do { if (DBG == 3 && n_stamp < 8) { __builtin_amdgcn_sched_barrier(0); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
     const int sf = l16 < NIF ? l16 : NIF - 1;   // lane's face (lanes 12..15 redo face 11 and write nothing)
+    // Which 4-node groups this wave walks.  Workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own
+    // L2: with the plain grid stride the 8 faces / 8 cells a node shares with its neighbours in the next mesh row would
+    // be fetched by a different XCD every time.  So XCD x takes the x-th CONTIGUOUS eighth of the node list and its
+    // waves interleave inside that range: neighbouring rows of the mesh meet in one L2 a few passes apart.
+    int32_t wg_first, wg_end, wg_step;
+    if ((gridDim.x & 7) == 0) {
+        const int32_t xcd = blockIdx.x & 7, per = (n_groups + 7) / 8;
+        wg_step = (int32_t)(gridDim.x >> 3) * wpb;
+        wg_first = xcd * per + (int32_t)(blockIdx.x >> 3) * wpb + wave;
+        wg_end = (xcd + 1) * per < n_groups ? (xcd + 1) * per : n_groups;
+    } else {
+        wg_step = (int32_t)gridDim.x * wpb;
+        wg_first = blockIdx.x * wpb + wave;
+        wg_end = n_groups;
+    }
     NodeFetch cur, nx;
     {
-        const int32_t wg0 = blockIdx.x * wpb + wave;
+        const int32_t wg0 = wg_first;
         cur.level0(nodes, wg0 * GPW + grp, count);
         cur.level1(g);
         cur.level2(g, l8, sf);
         cur.level3(g);
         cur.level4(g);
     }
-    for (int32_t wg = blockIdx.x * wpb + wave; wg < n_groups; wg += gridDim.x * wpb) {
+    for (int32_t wg = wg_first; wg < wg_end; wg += wg_step) {
         if (DBG == 3) n_stamp = 0;
         NIN_STAMP();
-        nx.level0(nodes, (wg + (int32_t)(gridDim.x * wpb)) * GPW + grp, count);   // a clamped (valid) node past the end
+        nx.level0(nodes, (wg + wg_step) * GPW + grp, count);   // a clamped (valid) node past the end
         const bool valid = cur.valid;
         const int32_t p = cur.p, eb = cur.eb;
         const double xv0 = cur.xv[0], xv1 = cur.xv[1], xv2 = cur.xv[2];
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
         }
         lds_sync();
         NIN_STAMP();
-        if (DBG == 3 && blockIdx.x == 0 && threadIdx.x == 0 && wg == (int32_t)(blockIdx.x * wpb + wave) + 3 * (int32_t)(gridDim.x * wpb)) {
+        if (DBG == 3 && blockIdx.x == 0 && threadIdx.x == 0 && wg == wg_first + 3 * wg_step) {
             const int32_t p0 = nodes ? nodes[0] : 0;   // debug build only: 4th pass of wave 0, into the row of its 1st node
             for (int i = 0; i < n_stamp; ++i) out[g.esup_ptr[p0] + i] = 1.0e6 + (double)(stamps[i] - stamps[0]);
         }
@@ -522,8 +537,9 @@ int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int 
     constexpr int wpb = 4;
     const size_t dyn = (size_t)wpb * C::NODES_PER_WAVE * C::NODE_DOUBLES * sizeof(double);
     int64_t blocks = ((int64_t)count + wpb * C::NODES_PER_WAVE - 1) / (wpb * C::NODES_PER_WAVE);
-    const int64_t cap = 256 * 16;
+    const int64_t cap = 256;   // one 145 KB workgroup per CU is resident anyway: persistent, and blockIdx % 8 is the XCD
     if (blocks > cap) blocks = cap;
+    if (blocks > 8) blocks &= ~(int64_t)7;
     static const int max_blocks = getenv("NIN_GLS_MAX_BLOCKS") ? atoi(getenv("NIN_GLS_MAX_BLOCKS")) : 0;
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     static bool attr_set = false;
