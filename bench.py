@@ -321,6 +321,31 @@ def main():
             W, _ = I.interpolate("u", args.method)
             line["e2e_interpolate_s"] = round(time.time() - t0, 3)
             line["e2e_nnz"] = int(W.nnz)
+            del W, I
+            # context: GLS on the other mesh families of BASELINE.json's configs (block kernel)
+            if args.method == "gls":
+                other = {}
+                for name, make in (("kuhn_tets_40^3", lambda: M.tet_mesh(40, jitter=0.1)),
+                                   ("hex_pyramid_tet_mix_100x60x60", lambda: M.mixed_mesh(100, 60, 60, jitter=0.1))):
+                    mo = make()
+                    M.attach_fields(mo, "u", perm="ALH")
+                    Io = ninpol_amd.Interpolator(device=local_rank, grid_build="device")
+                    Io.load_mesh(mesh_obj=mo)
+                    po = Io.device_plan("u", "gls")
+                    oo = torch.empty(po.nnz, dtype=torch.float64, device=dev)
+                    no = torch.empty(po.n_points, dtype=torch.float64, device=dev)
+                    po.launch(oo.data_ptr(), no.data_ptr(), stream.cuda_stream)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    for _ in range(3):
+                        po.launch(oo.data_ptr(), no.data_ptr(), stream.cuda_stream)
+                    b.record(stream)
+                    torch.cuda.synchronize()
+                    ms = a.elapsed_time(b) / 3
+                    other[name] = {"cells": int(Io.grid.n_elems), "nodes": int(Io.grid.n_points), "kernel_ms": round(ms, 3),
+                                   "Mnodes_per_s": round(Io.grid.n_points / ms / 1e3, 2)}
+                    del Io, po, oo, no, mo
+                line["gls_other_meshes"] = other
         if world == 1 and args.cpu_sample > 0:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.method, args.cpu_sample, args.jitter)
