@@ -166,6 +166,23 @@ class Interpolator:
         self.is_grid_initialized = True
         self._log(f"Mesh loaded successfully: {self.grid.n_points} points and {self.grid.n_elems} elements.")
 
+    def load_arrays(self, points, cells, cell_data=None, point_data=None):
+        """`load_mesh` from plain arrays, no meshio object.  `cells` is a list of
+        (type name, (n, nodes per cell) int array) blocks in meshio's vertex order -- one block per type, as the
+        reference's `cell_data_dict` assumes -- `cell_data[var]` one array over all cells in block order (or a list
+        of per-block arrays), `point_data[var]` one array per node."""
+        from .mesh import Mesh, CellBlock
+        blocks = [CellBlock(t, np.asarray(d)) for t, d in cells]
+        cd = {}
+        for name, a in (cell_data or {}).items():
+            if isinstance(a, (list, tuple)):
+                cd[name] = [np.asarray(x) for x in a]
+            else:
+                a = np.asarray(a)
+                cuts = np.cumsum([len(b) for b in blocks])[:-1]
+                cd[name] = np.split(a, cuts)
+        self.load_mesh(mesh_obj=Mesh(np.asarray(points), blocks, point_data=dict(point_data or {}), cell_data=cd))
+
     def process_mesh(self, mesh):
         """interpolator.pyx:255-369, vectorised: fixed-width -1 padded connectivity + topology tables."""
         dim = T.mesh_dimension([b.type for b in mesh.cells])

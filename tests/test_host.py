@@ -174,3 +174,20 @@ def test_2d_mesh_host_grid_matches_oracle(lib, oracle_lib):
             assert getattr(I.grid, k) == getattr(o.grid, k), (be, k)
         for k in util.GRID_ARRAYS:
             np.testing.assert_array_equal(getattr(I.grid, k), getattr(o.grid, k), err_msg=f"{be}:{k}")
+
+
+def test_load_arrays_equals_load_mesh():
+    """the array-based entry builds the same tables and grid as the mesh-object entry."""
+    import ninpol_amd
+    from ninpol_amd import mesh as M
+    m = M.mixed_mesh(6, 4, 4, jitter=0.1, seed=1)
+    M.attach_fields(m, "u", perm="ALH", neumann_plane=(2, 0.0))
+    a = ninpol_amd.Interpolator()
+    a.load_mesh(mesh_obj=m)
+    b = ninpol_amd.Interpolator()
+    b.load_arrays(m.points, [(c.type, c.data) for c in m.cells],
+                  cell_data={k: np.concatenate(v) for k, v in m.cell_data.items()}, point_data=m.point_data)
+    assert a.variable_to_index == b.variable_to_index
+    assert np.array_equal(a.cells_data, b.cells_data) and np.array_equal(a.points_data, b.points_data)
+    for k in ("esup", "esup_ptr", "fsup", "inpofa", "centroids", "normal_faces"):
+        assert np.array_equal(getattr(a.grid, k), getattr(b.grid, k)), k
