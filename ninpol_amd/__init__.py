@@ -5,6 +5,7 @@
 from .grid import Grid
 from .interpolator import Interpolator
 from .mesh import CellBlock, Mesh
+from ._lib import NinpolError
 
-__all__ = ["Interpolator", "Grid", "Mesh", "CellBlock"]
+__all__ = ["Interpolator", "Grid", "Mesh", "CellBlock", "NinpolError"]
 __version__ = "0.1.0"

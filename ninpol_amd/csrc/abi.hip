@@ -388,6 +388,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         d.hex8.nodes = const_cast<int32_t *>(lp);
         if (d.hex8.count == P) d.hex8.nodes = nullptr;
     }
+    d.gls_too_large = rows_max[kGlsClasses - 1] > 1024;
     if (d.gls[kGlsClasses - 1].count) {
         d.gls_scratch_slots = 1024;
         d.gls_scratch_stride = need_max[kGlsClasses - 1] / 8;
@@ -446,6 +447,8 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     if (method != NIN_METHOD_GLS && method != NIN_METHOD_IDW && method != NIN_METHOD_LS)
         return fail(NIN_EINVAL, "unknown method %d", method);
     if (method == NIN_METHOD_GLS && !d.have_perm) return fail(NIN_ESTATE, "GLS needs permeability and diff_mag");
+    if (method == NIN_METHOD_GLS && d.gls_too_large)
+        return fail(NIN_ERANGE, "a node's GLS system has more than 1024 rows (more than ~100 cells around one node): beyond the fallback kernel");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipSetDevice(d.device));
     const int64_t P = g->h.n_points;

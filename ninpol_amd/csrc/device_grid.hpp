@@ -80,6 +80,7 @@ struct DeviceGrid {
     double *gls_scratch = nullptr;  // global-memory systems for the oversize class
     int64_t gls_scratch_stride = 0; // doubles per wave slot
     int32_t gls_scratch_slots = 0;
+    bool gls_too_large = false;     // some node's system has more rows than the scratch kernel handles (1024)
 };
 
 struct HostGrid;

@@ -142,6 +142,30 @@ def wedge_mesh(nx, ny=None, nz=None, lengths=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 
     return Mesh(pts, [CellBlock("wedge", w)])
 
 
+def wedge_fan(n_sectors, n_layers=2, jitter=0.0, seed=0):
+    """A disc of `n_sectors` triangles around its centre, extruded into `n_layers` layers of wedges: the interior
+    nodes on the axis have 2 * n_sectors cells and 5 * n_sectors faces around them -- the high-degree nodes that no
+    lattice generator produces (wide GLS systems: column slots 3-4, the global-scratch class)."""
+    rng = np.random.default_rng(seed)
+    th = 2.0 * np.pi * np.arange(n_sectors) / n_sectors
+    pts = []
+    for k in range(n_layers + 1):
+        z = k / n_layers
+        pts.append([0.0, 0.0, z])
+        pts.extend([[np.cos(t), np.sin(t), z] for t in th])
+    pts = np.asarray(pts, dtype=float)
+    if jitter:
+        pts[:, :2] += rng.uniform(-jitter, jitter, size=(len(pts), 2)) * (np.abs(pts[:, :1]) + np.abs(pts[:, 1:2]) > 0)
+    per = n_sectors + 1
+    w = []
+    for k in range(n_layers):
+        lo, hi = k * per, (k + 1) * per
+        for i in range(n_sectors):
+            a, b = 1 + i, 1 + (i + 1) % n_sectors
+            w.append([lo, lo + a, lo + b, hi, hi + a, hi + b])   # bottom triangle counter-clockwise from above
+    return Mesh(pts, [CellBlock("wedge", np.asarray(w, dtype=np.int64))])
+
+
 def mixed_mesh(nx, ny=None, nz=None, n_hex=None, lengths=(1.0, 1.0, 1.0), jitter=0.0, seed=0):
     """Conforming hex | transition | tet mesh along x.
 

@@ -130,6 +130,39 @@ def test_gpu_generic_kernel_on_hex(oracle_lib, monkeypatch):
     assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
 
 
+@pytest.mark.parametrize("sectors,layers", [(15, 3), (30, 3), (50, 2), (80, 2)])
+def test_gpu_gls_high_degree_nodes(oracle_lib, sectors, layers):
+    """Wedge fans: the axis nodes have 2 * sectors cells -- 91 / 181 / 301 / 481 unknowns -- which takes the block
+    kernel through its wider column slots (2, 3) and, past 256 columns, the wave kernel on global scratch."""
+    mesh = M.wedge_fan(sectors, layers, jitter=0.02, seed=sectors)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=3)
+    o = oracle_lib.OracleInterpolator("port", threads=4)
+    o.load_mesh(mesh)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    assert I.grid.MX_ELEMENTS_PER_POINT == 2 * sectors
+    for meth in ("idw", "ls", "gls"):
+        wo, no = o.prepare(meth, "u")
+        w, nw = I.prepare_interpolator(meth, "u", np.arange(I.grid.n_points))
+        tol = util.WEIGHT_RTOL if meth == "gls" else TIGHT
+        assert util.rowscaled_err(w, wo) <= tol, meth
+        assert util.rowscaled_err(nw, no) <= tol, meth
+
+
+def test_gpu_gls_oversize_node_is_an_error_not_a_crash():
+    """More than 1024 rows in one node's system is beyond the fallback kernel: NIN_ERANGE, nothing launched."""
+    import ninpol_amd
+    mesh = M.wedge_fan(120, 2)
+    M.attach_fields(mesh, "u", perm="LIN")
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    with pytest.raises(ninpol_amd.NinpolError) as e:
+        I.interpolate("u", "gls")
+    assert e.value.code == -5
+    W, _ = I.interpolate("u", "idw")      # the grid and the other methods are unaffected
+    assert W.shape == (I.grid.n_points, I.grid.n_elems)
+
+
 def test_gpu_apply_matches_matrix_product():
     """Interpolator.apply == interpolate().dot(u) (the reference callers' next step, analytical.py:236)."""
     mesh = M.mixed_mesh(10, 6, 6, jitter=0.1, seed=2)
