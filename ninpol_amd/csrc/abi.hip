@@ -389,6 +389,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         if (d.hex8.count == P) d.hex8.nodes = nullptr;
     }
     d.gls_too_large = rows_max[kGlsClasses - 1] > 1024;
+    if ((rc = dev_alloc(d, &d.gls_queue, (size_t)kGlsQueueInts))) return rc;
     if (d.gls[kGlsClasses - 1].count) {
         d.gls_scratch_slots = 1024;
         d.gls_scratch_stride = need_max[kGlsClasses - 1] / 8;
@@ -459,7 +460,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
         else {
-            rc = launch_gls_hex8(d.v, d.hex8.nodes, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
+            rc = launch_gls_hex8(d.v, d.hex8.nodes, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue, stream);
             for (int c = 0; c < kGlsClasses && !rc; ++c) {
                 rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             }
@@ -499,7 +500,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         const int32_t cnt = (int32_t)lists[c].size();
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
-        else if ((int)c == kGlsClasses) rc = launch_gls_hex8(d.v, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
+        else if ((int)c == kGlsClasses) rc = launch_gls_hex8(d.v, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue, stream);
         else rc = launch_class(d, (int)c, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
     }
     const hipError_t sy = hipStreamSynchronize(stream);   // the lists must outlive the kernels

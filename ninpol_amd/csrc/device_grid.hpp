@@ -33,6 +33,7 @@ struct GridView {  // passed to kernels by value
 #define NIN_HD
 #endif
 
+constexpr int kGlsQueueInts = 8 * 16;   // hex8 kernel: one work counter per XCD, each on its own 64-byte line
 constexpr int kGlsClasses = 5;  // four LDS budget classes (1 / 2 / 4 / 8 waves per node) + one global-scratch class
 // LDS bytes a node's system may take in class c and the waves per node the block kernel runs it with
 // (16 / 5 / 2 / 1 workgroups per CU); the last class keeps its systems in global-memory scratch.
@@ -80,6 +81,7 @@ struct DeviceGrid {
     double *gls_scratch = nullptr;  // global-memory systems for the oversize class
     int64_t gls_scratch_stride = 0; // doubles per wave slot
     int32_t gls_scratch_slots = 0;
+    int32_t *gls_queue = nullptr;   // [kGlsQueueInts]
     bool gls_too_large = false;     // some node's system has more rows than the scratch kernel handles (1024)
 };
 

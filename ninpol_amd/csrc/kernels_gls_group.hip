@@ -338,7 +338,8 @@ struct BackLoop<-1> {
 template <int DBG>
 __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                                int32_t count, int add_neumann,
-                                                               double *__restrict__ out, double *__restrict__ nws) {
+                                                               double *__restrict__ out, double *__restrict__ nws,
+                                                               int32_t *__restrict__ queue) {
     using C = Hex8;
     constexpr int NE = C::NE, NIF = C::NIF, M = C::M, NA = C::NA, SLOTS = C::SLOTS, HR = C::HR;
     extern __shared__ double smem[];
@@ -357,33 +358,42 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
 #define NIN_STAMP() do { if (DBG == 3 && n_stamp < 8) { __builtin_amdgcn_sched_barrier(0); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
     const int sf = l16 < NIF ? l16 : NIF - 1;   // lane's face (lanes 12..15 redo face 11 and write nothing)
     // Which 4-node groups this wave walks.  Workgroups go round-robin over the 8 XCDs (blockIdx % 8), each with its own
-    // L2: with the plain grid stride the 8 faces / 8 cells a node shares with its neighbours in the next mesh row would
-    // be fetched by a different XCD every time.  So XCD x takes the x-th CONTIGUOUS eighth of the node list and its
-    // waves interleave inside that range: neighbouring rows of the mesh meet in one L2 a few passes apart.
-    int32_t wg_first, wg_end, wg_step;
+    // L2: with a plain grid stride the 8 faces / 8 cells a node shares with its neighbours in the next mesh row would
+    // be fetched by a different XCD every time.  So XCD x takes the x-th CONTIGUOUS eighth of the node list, and its
+    // waves pull consecutive groups off a per-XCD counter: neighbouring mesh rows meet in one L2 a few passes apart,
+    // and a CU that starts late (another kernel -- the all-gather of the previous step -- holds it) simply takes
+    // fewer groups instead of stretching the launch.  Every wave ends when its counter passes the range.
+    int32_t wg_lo, wg_end;
+    int32_t *q;
     if ((gridDim.x & 7) == 0) {
         const int32_t xcd = blockIdx.x & 7, per = (n_groups + 7) / 8;
-        wg_step = (int32_t)(gridDim.x >> 3) * wpb;
-        wg_first = xcd * per + (int32_t)(blockIdx.x >> 3) * wpb + wave;
+        wg_lo = xcd * per;
         wg_end = (xcd + 1) * per < n_groups ? (xcd + 1) * per : n_groups;
+        q = queue + 16 * xcd;   // one counter per 64-byte line
     } else {
-        wg_step = (int32_t)gridDim.x * wpb;
-        wg_first = blockIdx.x * wpb + wave;
+        wg_lo = 0;
         wg_end = n_groups;
+        q = queue;
     }
+    auto grab = [&]() -> int32_t {
+        int32_t v = 0;
+        if (lane == 0) v = atomicAdd(q, 1);
+        return wg_lo + __builtin_amdgcn_readfirstlane(v);
+    };
     NodeFetch cur, nx;
+    int32_t wg = grab();
     {
-        const int32_t wg0 = wg_first;
-        cur.level0(nodes, wg0 * GPW + grp, count);
+        cur.level0(nodes, wg * GPW + grp, count);
         cur.level1(g);
         cur.level2(g, l8, sf);
         cur.level3(g);
         cur.level4(g);
     }
-    for (int32_t wg = wg_first; wg < wg_end; wg += wg_step) {
+    for (int32_t pass = 0; wg < wg_end; ++pass) {
         if (DBG == 3) n_stamp = 0;
         NIN_STAMP();
-        nx.level0(nodes, (wg + wg_step) * GPW + grp, count);   // a clamped (valid) node past the end
+        const int32_t wg_next = grab();
+        nx.level0(nodes, wg_next * GPW + grp, count);   // past the end: a clamped (valid) node, never used
         const bool valid = cur.valid;
         const int32_t p = cur.p, eb = cur.eb;
         const double xv0 = cur.xv[0], xv1 = cur.xv[1], xv2 = cur.xv[2];
@@ -520,19 +530,21 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
         }
         lds_sync();
         NIN_STAMP();
-        if (DBG == 3 && blockIdx.x == 0 && threadIdx.x == 0 && wg == wg_first + 3 * wg_step) {
+        if (DBG == 3 && blockIdx.x == 0 && threadIdx.x == 0 && pass == 3) {
             const int32_t p0 = nodes ? nodes[0] : 0;   // debug build only: 4th pass of wave 0, into the row of its 1st node
             for (int i = 0; i < n_stamp; ++i) out[g.esup_ptr[p0] + i] = 1.0e6 + (double)(stamps[i] - stamps[0]);
         }
         cur = nx;
+        wg = wg_next;
     }
 }
 
 }  // namespace
 
 int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out,
-                    double *nws, hipStream_t stream) {
+                    double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
+    if (hipMemsetAsync(queue, 0, kGlsQueueInts * sizeof(int32_t), stream) != hipSuccess) return -3;
     using C = Hex8;
     constexpr int wpb = 4;
     const size_t dyn = (size_t)wpb * C::NODES_PER_WAVE * C::NODE_DOUBLES * sizeof(double);
@@ -551,12 +563,12 @@ int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int 
         attr_set = true;
     }
     static const int dbg = getenv("NIN_GLS_DEBUG_MODE") ? atoi(getenv("NIN_GLS_DEBUG_MODE")) : 0;
-    if (dbg == 3) hipLaunchKernelGGL(nin_gls_group_kernel<3>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws);
-    else if (dbg == 1) hipLaunchKernelGGL(nin_gls_group_kernel<1>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws);
-    else if (dbg == 2) hipLaunchKernelGGL(nin_gls_group_kernel<2>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws);
+    if (dbg == 3) hipLaunchKernelGGL(nin_gls_group_kernel<3>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws, queue);
+    else if (dbg == 1) hipLaunchKernelGGL(nin_gls_group_kernel<1>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws, queue);
+    else if (dbg == 2) hipLaunchKernelGGL(nin_gls_group_kernel<2>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count, add_neumann, out, nws, queue);
     else
     hipLaunchKernelGGL(nin_gls_group_kernel<0>, dim3((unsigned)blocks), dim3(64 * wpb), dyn, stream, g, nodes, count,
-                       add_neumann, out, nws);
+                       add_neumann, out, nws, queue);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -23,8 +23,9 @@ int launch_gls_block(const GridView &g, const int32_t *nodes, int32_t count, int
                      int32_t lds_bytes, int add_neumann, double *out, double *nws, hipStream_t stream);
 const char *kernel_name_gls_block();
 // the register-resident group kernel for (8 cells, 12 internal faces) nodes, kernels_gls_group.hip
+// `queue`: kGlsQueueInts device ints (one work counter per XCD on its own cache line), zeroed by the launcher
 int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out,
-                    double *nws, hipStream_t stream);
+                    double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_hex8();
 // out[j] += nws[row(j)] for IDW / LS is a no-op (their neumann_ws is 0): nothing to launch.
 
