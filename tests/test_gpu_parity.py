@@ -176,3 +176,34 @@ def test_gpu_apply_matches_matrix_product():
         ref = W.dot(u)
         np.testing.assert_array_equal(nws, nws2)
         assert np.abs(vals - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), meth
+
+
+def test_gpu_integration_md_plugin_stub_runs_verbatim():
+    """the ctypes plugin a ninpol maintainer would add is executed as printed (only the
+    library path is made absolute) against ninpol's 9-argument plugin convention, and must fill the dense
+    (n_target, MX_ELEMENTS_PER_POINT) table exactly as our own Interpolator does."""
+    import os, re
+    import ninpol_amd
+    from ninpol_amd import build as nbuild
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## B."):]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libninpol_amd.so")', f'ctypes.CDLL({nbuild.LIB!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#B", "exec"), ns)
+    mesh = M.mixed_mesh(8, 5, 5, jitter=0.1, seed=4)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=6)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    args = I.process_mesh(mesh)
+    g = I.grid
+    for meth in ("gls", "idw", "ls"):
+        plug = ns["AMDPlugin"](meth, args, mesh.points, device=0)
+        weights = np.zeros((g.n_points, g.MX_ELEMENTS_PER_POINT))
+        nws = np.zeros(g.n_points)
+        plug.prepare(g, I.cells_data, I.points_data, I.faces_data, I.variable_to_index, "u",
+                     np.arange(g.n_points), weights, nws)
+        w, nw = I.prepare_interpolator(meth, "u", np.arange(g.n_points))
+        assert np.array_equal(weights, w, equal_nan=True), meth
+        assert np.array_equal(nws, nw, equal_nan=True), meth
