@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=64, help="edge of the CPU-baseline sample mesh (0 = skip)")
     ap.add_argument("--grid-build", default="host", choices=["host", "device"],
                     help="where the Grid connectivity is built (north_star: host, pushed to HBM; device = SURVEY 8 f1)")
+    ap.add_argument("--no-other-meshes", action="store_true",
+                    help="skip the GLS-on-tet/mixed-mesh context (profiling runs: keeps per-kernel averages clean)")
     ap.add_argument("--no-extras", action="store_true", help="skip the IDW/LS context numbers and the e2e timing")
     ap.add_argument("--check", action="store_true",
                     help="(small --edge only) rank 0 recomputes the whole mesh on its GPU and compares the gathered triplets")
@@ -323,7 +325,7 @@ def main():
             line["e2e_nnz"] = int(W.nnz)
             del W, I
             # context: GLS on the other mesh families of BASELINE.json's configs (block kernel)
-            if args.method == "gls":
+            if args.method == "gls" and not args.no_other_meshes:
                 other = {}
                 for name, make in (("kuhn_tets_40^3", lambda: M.tet_mesh(40, jitter=0.1)),
                                    ("hex_pyramid_tet_mix_100x60x60", lambda: M.mixed_mesh(100, 60, 60, jitter=0.1))):
