@@ -146,6 +146,21 @@ def test_no_cpu_fallback(lib):
     assert ei.value.code == lib.NIN_ENODEVICE
 
 
+def test_device_grid_build_has_no_cpu_fallback(lib):
+    """`grid_build="device"` without a GPU is NIN_ENODEVICE, not a silent host build."""
+    import ninpol_amd
+    if lib.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by tests/test_gpu_grid_device.py")
+    mesh = M.hex_mesh(3)
+    M.attach_fields(mesh, "u")
+    I = ninpol_amd.Interpolator(grid_build="device")
+    with pytest.raises(lib.NinpolError) as ei:
+        I.load_mesh(mesh_obj=mesh)
+    assert ei.value.code == lib.NIN_ENODEVICE
+    with pytest.raises(ValueError):
+        ninpol_amd.Interpolator(grid_build="somewhere")
+
+
 def test_product_never_imports_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ninpol_amd")):
