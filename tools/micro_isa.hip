@@ -1,5 +1,6 @@
 // Issue-rate microbenchmarks for the GLS kernels' building blocks (gfx950): cycles per wave-instruction with
-// 1, 2 and 4 waves per SIMD.   hipcc --offload-arch=gfx950 -O3 tools/micro_isa.hip -o /tmp/micro_isa && /tmp/micro_isa
+// 1, 2 and 4 waves per SIMD.   mkdir -p tools/_bin && hipcc --offload-arch=gfx950 -O3 -w tools/micro_isa.hip -o tools/_bin/micro_isa  (git-ignored; travels to the
+// GPU box with the tree), then on the box: tools/_bin/micro_isa
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
