@@ -90,8 +90,13 @@ class ShardedInterpolator:
     make_interpolator: factory for the per-rank compute object (default: ninpol_amd.Interpolator on
     this rank's GPU).  The CPU tests inject the oracle here; the product path never does."""
 
-    def __init__(self, group=None, device=None, make_interpolator=None):
+    def __init__(self, group=None, device=None, make_interpolator=None, comm_on_host=False, grid_build="host"):
+        """device: this rank's GPU (None: the injected compute object runs on the host -- CPU tests only).
+        comm_on_host: stage the all-gather through host tensors (a gloo group next to GPU compute, e.g. several
+        ranks rehearsing on one GPU); default: the collective runs on the compute device (backend nccl = RCCL)."""
         import torch.distributed as dist
+        self.comm_on_host = bool(comm_on_host)
+        self.grid_build = grid_build
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -107,7 +112,7 @@ class ShardedInterpolator:
         self.n_elems = int(sum(len(b.data) for b in mesh_obj.cells if b.type in T.TYPES_PER_DIMENSION[dim]))
         if self._make is None:
             from .interpolator import Interpolator
-            self.local = Interpolator(device=self.device if self.device is not None else 0)
+            self.local = Interpolator(device=self.device if self.device is not None else 0, grid_build=self.grid_build)
         else:
             self.local = self._make()
         self.local.load_mesh(mesh_obj=sub)
@@ -117,7 +122,7 @@ class ShardedInterpolator:
         W, nws = self.local.interpolate(variable, method)          # local (P_loc x E_loc), zeros eliminated
         W = W.tocsr()[self.owned]                                  # rows of the owned block, ascending
         cols = self.cell_ids[W.indices].astype(np.int32)           # local -> global cell id
-        dev = torch.device("cpu") if self.device is None else torch.device("cuda", self.device)
+        dev = torch.device("cpu") if (self.device is None or self.comm_on_host) else torch.device("cuda", self.device)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         row_nnz = np.diff(W.indptr).astype(np.int32)
         pieces = allgatherv([t(W.data), t(cols)], group=self.group)
