@@ -433,8 +433,9 @@ int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_m
 static int launch_class(DeviceGrid &d, int c, const int32_t *nodes, int32_t count, int add_neumann, double *out,
                         double *nws, hipStream_t stream) {
     const auto &k = d.gls[c];
-    if (c < kGlsClasses - 1)
-        return launch_gls_block(d.v, nodes, count, k.waves, k.col_slots, k.lds_bytes, add_neumann, out, nws, stream);
+    if (c < kGlsClasses - 1)   // work counter: ints 1..4 of the queue block (the hex8 kernel uses 0, 16, 32, ...)
+        return launch_gls_block(d.v, nodes, count, k.waves, k.col_slots, k.lds_bytes, add_neumann, out, nws,
+                                d.gls_queue + 1 + c, stream);
     return launch_gls_class(d.v, nodes, count, 0, k.rows_per_lane, add_neumann, out, nws, d.gls_scratch,
                             d.gls_scratch_stride, d.gls_scratch_slots, stream);
 }
@@ -460,6 +461,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
         else {
+            HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
             rc = launch_gls_hex8(d.v, d.hex8.nodes, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue, stream);
             for (int c = 0; c < kGlsClasses && !rc; ++c) {
                 rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
@@ -494,6 +496,10 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     HIP_TRY(hipMalloc((void **)&dl0, flat.size() * 4));
     const hipError_t cp = hipMemcpy(dl0, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
     if (cp != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemcpy: %s", hipGetErrorString(cp)); }
+    if (method == NIN_METHOD_GLS) {
+        const hipError_t qe = hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream);
+        if (qe != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemsetAsync: %s", hipGetErrorString(qe)); }
+    }
     for (size_t c = 0; c < lists.size() && !rc; ++c) {
         if (lists[c].empty()) continue;
         const int32_t *dl = dl0 + first[c];

@@ -260,7 +260,7 @@ template <int NW, int CS>
 __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                                  int32_t count, int add_neumann,
                                                                  double *__restrict__ out, double *__restrict__ nws,
-                                                                 int dbg) {
+                                                                 int32_t *__restrict__ queue, int dbg) {
     extern __shared__ double smem[];
     (void)dbg;
     constexpr bool DB = NW != 4;   // partial dots double-buffered (one barrier per step) except where LDS is tight
@@ -268,7 +268,31 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
     const int lane = tid & 63;
     const int wave = ufirst(tid >> 6);
 
-    for (int32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    // NW > 1: nodes come off an atomic counter, CH at a time (Dirichlet nodes cost nothing, interior ones up to ~100 us:
+    // a static stride leaves a ~10 % tail).  The NEXT chunk is fetched while this one is worked on; its index travels
+    // through the first LDS word, ordered by the workgroup barriers that are there anyway.  NW == 1 (small systems,
+    // mostly boundary nodes that are skipped at once): a plain grid stride -- there the counter itself would be the
+    // bottleneck and there is no tail to speak of.
+    constexpr int CH = NW == 2 ? 4 : 1;
+    volatile int32_t *slot = reinterpret_cast<volatile int32_t *>(smem);
+    double *const sys_lds = smem + 2;
+    int within = 0;
+    auto next_node = [&](int32_t idx) -> int32_t {
+        group_sync<NW>();          // the node is done (its LDS may be reused) and the prefetched chunk index has landed
+        if (NW == 1) return idx + (int32_t)gridDim.x;
+        if (++within < CH) return idx + 1;
+        within = 0;
+        return ufirst(*slot) * CH;
+    };
+    if (NW > 1) {
+        if (tid == 0) *slot = atomicAdd(queue, 1);
+        group_sync<NW>();
+    }
+    for (int32_t idx = NW == 1 ? (int32_t)blockIdx.x : ufirst(*slot) * CH; idx < count; idx = next_node(idx)) {
+        if (NW > 1 && within == 0) {
+            group_sync<NW>();      // every wave holds idx: the slot may be rewritten
+            if (tid == 0) *slot = atomicAdd(queue, 1);
+        }
         const int32_t p = ufirst(nodes ? nodes[idx] : idx);
         const int32_t eb = ufirst(g.esup_ptr[p]), ne = ufirst(g.esup_ptr[p + 1]) - eb;
         const int32_t fb = ufirst(g.fsup_ptr[p]), nf = ufirst(g.fsup_ptr[p + 1]) - fb;
@@ -297,8 +321,8 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
         }
         Sys s;
         const int ld = m | 1;   // odd pitch: the 64 lanes of a row access hit 64 different 8-byte bank pairs
-        s.A = smem;
-        s.aux = smem + (size_t)(n + 1) * ld;
+        s.A = sys_lds;
+        s.aux = sys_lds + (size_t)(n + 1) * ld;
         s.n = n; s.m = m; s.ld = ld; s.lane = lane; s.wave = wave;
 #ifdef NIN_BLOCK_STAMPS
         s.stamps = (dbg >> 8) == p ? nws : nullptr;   // NIN_GLS_BLOCK_DEBUG = node << 8: that node's block records
@@ -480,13 +504,12 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             if (lane == 0) nws[p] = nwv;
 #endif
         }
-        group_sync<NW>();   // the next node reuses the LDS
     }
 }
 
 template <int NW, int CS>
 int launch_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes, int add_neumann,
-                 double *out, double *nws, hipStream_t stream) {
+                 double *out, double *nws, int32_t *queue, hipStream_t stream) {
     auto kern = nin_gls_block_kernel<NW, CS>;
     static const int dbg = getenv("NIN_GLS_BLOCK_DEBUG") ? atoi(getenv("NIN_GLS_BLOCK_DEBUG")) : 0;
     if (lds_bytes > 48 * 1024) {
@@ -502,18 +525,18 @@ int launch_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t
     static const int max_blocks = getenv("NIN_GLS_BLOCK_MAX_BLOCKS") ? atoi(getenv("NIN_GLS_BLOCK_MAX_BLOCKS")) : 0;
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;   // diagnostic: occupancy experiments
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), (size_t)lds_bytes, stream, g, nodes, count, add_neumann,
-                       out, nws, dbg);
+                       out, nws, queue, dbg);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 template <int NW>
 int launch_block_cs(int cs, const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes, int add_neumann,
-                    double *out, double *nws, hipStream_t stream) {
+                    double *out, double *nws, int32_t *queue, hipStream_t stream) {
     switch (cs) {
-        case 1: return launch_block<NW, 1>(g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
-        case 2: return launch_block<NW, 2>(g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
-        case 3: return launch_block<NW, 3>(g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
-        case 4: return launch_block<NW, 4>(g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+        case 1: return launch_block<NW, 1>(g, nodes, count, lds_bytes, add_neumann, out, nws, queue, stream);
+        case 2: return launch_block<NW, 2>(g, nodes, count, lds_bytes, add_neumann, out, nws, queue, stream);
+        case 3: return launch_block<NW, 3>(g, nodes, count, lds_bytes, add_neumann, out, nws, queue, stream);
+        case 4: return launch_block<NW, 4>(g, nodes, count, lds_bytes, add_neumann, out, nws, queue, stream);
     }
     return -5;
 }
@@ -521,13 +544,13 @@ int launch_block_cs(int cs, const GridView &g, const int32_t *nodes, int32_t cou
 }  // namespace
 
 int launch_gls_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t waves, int32_t col_slots,
-                     int32_t lds_bytes, int add_neumann, double *out, double *nws, hipStream_t stream) {
+                     int32_t lds_bytes, int add_neumann, double *out, double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
     switch (waves) {
-        case 1: return launch_block_cs<1>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
-        case 2: return launch_block_cs<2>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
-        case 4: return launch_block_cs<4>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
-        case 8: return launch_block_cs<8>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, stream);
+        case 1: return launch_block_cs<1>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, queue, stream);
+        case 2: return launch_block_cs<2>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, queue, stream);
+        case 4: return launch_block_cs<4>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, queue, stream);
+        case 8: return launch_block_cs<8>(col_slots, g, nodes, count, lds_bytes, add_neumann, out, nws, queue, stream);
     }
     return -1;
 }

@@ -544,7 +544,6 @@ __global__ __launch_bounds__(256, 1) void nin_gls_group_kernel(GridView g, const
 int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out,
                     double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
-    if (hipMemsetAsync(queue, 0, kGlsQueueInts * sizeof(int32_t), stream) != hipSuccess) return -3;
     using C = Hex8;
     constexpr int wpb = 4;
     const size_t dyn = (size_t)wpb * C::NODES_PER_WAVE * C::NODE_DOUBLES * sizeof(double);

@@ -19,11 +19,12 @@ int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int
                      int32_t rows_per_lane, int add_neumann, double *out, double *nws,
                      double *scratch, int64_t scratch_stride, int32_t scratch_slots, hipStream_t stream);
 // the block kernel (kernels_gls_block.hip): one node per workgroup of `waves` wavefronts, system in LDS
+// `queue`: one zeroed device int (the launch's work counter)
 int launch_gls_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t waves, int32_t col_slots,
-                     int32_t lds_bytes, int add_neumann, double *out, double *nws, hipStream_t stream);
+                     int32_t lds_bytes, int add_neumann, double *out, double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_block();
 // the register-resident group kernel for (8 cells, 12 internal faces) nodes, kernels_gls_group.hip
-// `queue`: kGlsQueueInts device ints (one work counter per XCD on its own cache line), zeroed by the launcher
+// `queue`: kGlsQueueInts zeroed device ints (one work counter per XCD, each on its own cache line)
 int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out,
                     double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_hex8();
