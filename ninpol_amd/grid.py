@@ -125,6 +125,11 @@ class Grid:
         self._cache[name] = a
         return a
 
+    @property
+    def nnz_esup(self):
+        """len(esup) without bringing the array to the host (a device-built grid mirrors arrays lazily)."""
+        return self._scalar("nnz_esup")
+
     def __getattr__(self, name):
         if name in _SCALARS:
             return self._scalar(name)

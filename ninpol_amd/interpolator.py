@@ -84,7 +84,7 @@ def _run_weights(grid, method, cells_data, points_data, variable_to_index, varia
     P = grid.n_points
     targets = np.ascontiguousarray(target_points, dtype=DTYPE_I)
     full = len(targets) == 0 or (len(targets) == P and np.array_equal(targets, np.arange(P)))
-    csr = np.empty(len(grid.esup), dtype=DTYPE_F)
+    csr = np.empty(grid.nnz_esup, dtype=DTYPE_F)
     nws = np.empty(P, dtype=DTYPE_F)
     _lib.check(L.nin_weights_host(grid._h, _lib.METHOD_ID[method], None if full else _ptr(targets),
                                   0 if full else len(targets), int(bool(add_neumann)), _ptr(csr), _ptr(nws)))
@@ -305,17 +305,23 @@ class Interpolator:
             raise ValueError(f"Variable '{variable}' has more than one dimension. Vector data not supported yet.")
         self._log(f"Interpolating variable '{variable}' using method '{method}'")
         g = self.grid
+        if method == "gls" and g.dim == 2:
+            # the reference's 2-D GLS system is rank deficient by construction (the z-gradient unknowns are tied only
+            # to each other) and what dgels returns for it is an accident of its singularity exit: not reproduced
+            import warnings
+            warnings.warn("GLS on a 2-D mesh: the reference's result there is undefined (rank-deficient system); "
+                          "values will not match ninpol's", RuntimeWarning, stacklevel=2)
         P, E = g.n_points, g.n_elems
         if g.device < 0:
             g.to_device(self.device)
         t0 = time.time()
         full = len(target_points) == P and np.array_equal(target_points, np.arange(P))
-        idx_t = np.int32 if max(len(g.esup), E, P) < np.iinfo(np.int32).max else np.int64
+        idx_t = np.int32 if max(g.nnz_esup, E, P) < np.iinfo(np.int32).max else np.int64
         if full and idx_t is np.int32:
             # one native call: kernel with `data[j] = weights + neumann_ws[row]` (interpolator.pyx:618) fused, then the
             # device-side csr_matrix + eliminate_zeros (interpolator.pyx:622-624); only the surviving entries cross PCIe
             _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable)
-            nnz_max = len(g.esup)
+            nnz_max = g.nnz_esup
             indptr = np.empty(P + 1, dtype=np.int32)
             indices = np.empty(nnz_max, dtype=np.int32)
             data = np.empty(nnz_max, dtype=DTYPE_F)
