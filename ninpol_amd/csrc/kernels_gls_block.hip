@@ -512,9 +512,11 @@ int launch_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t
                  double *out, double *nws, int32_t *queue, hipStream_t stream) {
     auto kern = nin_gls_block_kernel<NW, CS>;
     static const int dbg = getenv("NIN_GLS_BLOCK_DEBUG") ? atoi(getenv("NIN_GLS_BLOCK_DEBUG")) : 0;
-    if (lds_bytes > 48 * 1024) {
+    static int lds_allowed = 48 * 1024;   // per instantiation: raise the dynamic-LDS limit once per new maximum
+    if (lds_bytes > lds_allowed) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return -3;
+        lds_allowed = lds_bytes;
     }
     int per_cu = (160 * 1024) / (lds_bytes < 1024 ? 1024 : lds_bytes);
     const int wave_cap = 32 / NW;
