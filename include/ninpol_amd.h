@@ -99,7 +99,8 @@ int nin_grid_device(const nin_grid *g); /* device id or -1 */
 /* Per-call fields the plugins read from the data tables (idw.pyx:27-28, ls.pyx:27-28,
  * gls.pyx:47-59): permeability[E][3][3] row-major and diff_mag[E] (may be NULL for IDW / LS),
  * neumann_flag[P] (the points_data row, cast to integer like `.astype(int)`), neumann_val[P]
- * (may be NULL for IDW / LS).  Host pointers; uploaded to the grid's device. */
+ * (may be NULL for IDW / LS).  Host pointers; uploaded to the grid's device.  permeability / diff_mag NULL leaves
+ * the copies already on the device in place (they belong to the mesh, not to the variable). */
 int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_mag,
                    const double *neumann_flag, const double *neumann_val);
 

@@ -420,10 +420,10 @@ int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_m
         fl[p] = (uint8_t)((h.boundary_points[p] ? 1 : 0) | (as_int != 0 ? 2 : 0));
     }
     HIP_TRY(hipMemcpy(const_cast<uint8_t *>(d.v.flags), fl.data(), (size_t)P, hipMemcpyHostToDevice));
-    d.have_perm = permeability && diff_mag;
-    if (d.have_perm) {
+    if (permeability && diff_mag) {   // NULL keeps what is resident (0.8 GB at 10 M cells: callers upload it once per mesh)
         HIP_TRY(hipMemcpy(const_cast<double *>(d.v.perm), permeability, (size_t)E * 9 * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(const_cast<double *>(d.v.diff_mag), diff_mag, (size_t)E * 8, hipMemcpyHostToDevice));
+        d.have_perm = true;
     }
     d.fields_set = true;
     return NIN_OK;

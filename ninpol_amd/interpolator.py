@@ -69,12 +69,21 @@ def _upload_fields(grid, method, cells_data, points_data, variable_to_index, var
     v2i = variable_to_index
     flag = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_flag_" + variable]][:P], dtype=DTYPE_F)
     perm = dmag = nval = None
+    key = None
     if method == "gls":
         cd = np.asarray(cells_data)
         perm = np.ascontiguousarray(cd[v2i["cells"]["permeability"]][:E * 9], dtype=DTYPE_F)
         dmag = np.ascontiguousarray(cd[v2i["cells"]["diff_mag"]][:E], dtype=DTYPE_F)
         nval = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_" + variable]][:P], dtype=DTYPE_F)
+        # permeability and diff_mag belong to the mesh: 0.8 GB at 10 M cells, uploaded once.  The key is the
+        # buffer's address and size plus a strided sample of its values, so a rebuilt or edited table goes up again.
+        step = max(1, perm.size // 8192)
+        key = (perm.__array_interface__["data"][0], perm.size, perm[::step].tobytes(), dmag[::max(1, dmag.size // 8192)].tobytes())
+        if getattr(grid, "_perm_key", None) == key and grid.device >= 0:
+            perm = dmag = None
     _lib.check(L.nin_fields_set(grid._h, _ptr(perm), _ptr(dmag), _ptr(flag), _ptr(nval)))
+    if key is not None:
+        grid._perm_key = key
 
 
 def _run_weights(grid, method, cells_data, points_data, variable_to_index, variable, target_points, add_neumann):

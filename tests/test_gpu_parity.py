@@ -207,3 +207,27 @@ def test_gpu_integration_md_plugin_stub_runs_verbatim():
         w, nw = I.prepare_interpolator(meth, "u", np.arange(g.n_points))
         assert np.array_equal(weights, w, equal_nan=True), meth
         assert np.array_equal(nws, nw, equal_nan=True), meth
+
+
+def test_gpu_permeability_stays_resident_and_follows_edits():
+    """interpolate() uploads permeability / diff_mag once per mesh; a table that is rebuilt or edited in place is
+    uploaded again (the cache key samples the values)."""
+    mesh = M.hex_mesh(7, jitter=0.1, seed=2)
+    M.attach_fields(mesh, "u", perm="ALH")
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    W1, _ = I.interpolate("u", "gls")
+    key = I.grid._perm_key
+    W2, _ = I.interpolate("u", "gls")
+    assert I.grid._perm_key == key and np.array_equal(W1.data, W2.data)
+    row = I.variable_to_index["cells"]["permeability"]
+    I.cells_data[row, :I.grid.n_elems * 9] *= 1.0 + 0.3 * np.tile(np.arange(9) % 4 == 0, I.grid.n_elems)   # scale the diagonals
+    I.cells_data[I.variable_to_index["cells"]["diff_mag"], :I.grid.n_elems] = I.compute_diffusion_magnitude(
+        I.cells_data[row, :I.grid.n_elems * 9].reshape(-1, 9))
+    W3, _ = I.interpolate("u", "gls")
+    assert I.grid._perm_key != key
+    J = _interp()                      # the same edited tables through a fresh object
+    J.load_mesh(mesh_obj=mesh)
+    J.cells_data[:] = I.cells_data
+    W4, _ = J.interpolate("u", "gls")
+    assert np.array_equal(W3.data, W4.data) and not np.array_equal(W3.data, W1.data)
