@@ -19,6 +19,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <parallel/algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -406,7 +407,6 @@ void HostGrid::build_inedel() {
     const int64_t E = n_elems;
     inedel.assign((size_t)E * kMaxEdgesPerElement, -1);
     inpoed.clear();
-    std::unordered_map<int, int> dict;
     auto myhash = [](const int64_t *vec, int len) -> size_t {
         size_t seed = (size_t)len;
         for (int i = 0; i < len; ++i) {
@@ -418,27 +418,82 @@ void HostGrid::build_inedel() {
         }
         return seed;
     };
+    // The reference walks (element, local edge) in order and gives a new id to every key it has not seen
+    // (grid.pyx:527-580).  Same ids without the serial map: position of every pair in that walk, sort (key, position),
+    // the head of each key group is its first sight, and the id is the rank of that first sight among all of them.
+    std::vector<int64_t> start((size_t)E + 1, 0);
+    for (int64_t i = 0; i < E; ++i) start[i + 1] = start[i] + nedel[etype[i]];
+    const int64_t N = start[E];
+    if (N >= (int64_t)1 << 32) {   // positions no longer fit the packed sort key: the reference's own serial walk
+        std::unordered_map<int, int> dict;
+        for (int64_t i = 0; i < E; ++i) {
+            const int t = etype[i];
+            for (int j = 0; j < nedel[t]; ++j) {
+                int64_t ed[2] = {inpoel[i * 8 + lpoed[t][j][0]], inpoel[i * 8 + lpoed[t][j][1]]};
+                int64_t sd[2] = {ed[0], ed[1]};
+                if (ed[0] > ed[1]) std::swap(sd[0], sd[1]);
+                const int key = (int)myhash(sd, 2);
+                auto it = dict.find(key);
+                int idx;
+                if (it == dict.end()) {
+                    idx = (int)dict.size();
+                    dict.emplace(key, idx);
+                    inpoed.push_back((int32_t)ed[0]);
+                    inpoed.push_back((int32_t)ed[1]);
+                } else {
+                    idx = it->second;
+                }
+                inedel[i * kMaxEdgesPerElement + j] = idx;
+            }
+        }
+        n_edges = (int64_t)dict.size();
+        edges_built = true;
+        return;
+    }
+    std::vector<uint64_t> kv((size_t)N);   // (key as unsigned 32 bits) << 32 | position in the walk
+#pragma omp parallel for schedule(dynamic, 16384)
     for (int64_t i = 0; i < E; ++i) {
         const int t = etype[i];
         for (int j = 0; j < nedel[t]; ++j) {
-            int64_t ed[2] = {inpoel[i * 8 + lpoed[t][j][0]], inpoel[i * 8 + lpoed[t][j][1]]};
-            int64_t sd[2] = {ed[0], ed[1]};
-            if (ed[0] > ed[1]) std::swap(sd[0], sd[1]);
-            const int key = (int)myhash(sd, 2);
-            auto it = dict.find(key);
-            int idx;
-            if (it == dict.end()) {
-                idx = (int)dict.size();
-                dict.emplace(key, idx);
-                inpoed.push_back((int32_t)ed[0]);
-                inpoed.push_back((int32_t)ed[1]);
-            } else {
-                idx = it->second;
-            }
-            inedel[i * kMaxEdgesPerElement + j] = idx;
+            int64_t sd[2] = {inpoel[i * 8 + lpoed[t][j][0]], inpoel[i * 8 + lpoed[t][j][1]]};
+            if (sd[0] > sd[1]) std::swap(sd[0], sd[1]);
+            const uint32_t key = (uint32_t)(int)myhash(sd, 2);
+            kv[(size_t)(start[i] + j)] = ((uint64_t)key << 32) | (uint64_t)(start[i] + j);
         }
     }
-    n_edges = (int64_t)dict.size();
+    __gnu_parallel::sort(kv.begin(), kv.end());
+    std::vector<uint64_t> firsts;          // position of the first sight of every key, then sorted ascending
+    firsts.reserve((size_t)N / 3 + 16);
+    for (int64_t q = 0; q < N; ++q)
+        if (q == 0 || (kv[q] >> 32) != (kv[q - 1] >> 32)) firsts.push_back(kv[q] & 0xffffffffu);
+    std::vector<uint64_t> by_pos(firsts);
+    __gnu_parallel::sort(by_pos.begin(), by_pos.end());
+    n_edges = (int64_t)by_pos.size();
+    // element / local edge of a walk position (binary search over the per-element starts)
+    auto locate = [&](int64_t pos, int64_t *e, int *j) {
+        const int64_t i = (std::upper_bound(start.begin(), start.end(), pos) - start.begin()) - 1;
+        *e = i;
+        *j = (int)(pos - start[i]);
+    };
+    inpoed.resize((size_t)n_edges * 2);
+#pragma omp parallel for schedule(static)
+    for (int64_t id = 0; id < n_edges; ++id) {
+        int64_t e; int j;
+        locate((int64_t)by_pos[id], &e, &j);
+        const int t = etype[e];
+        inpoed[2 * id] = inpoel[e * 8 + lpoed[t][j][0]];       // the endpoints as first met, unsorted (grid.pyx:566-570)
+        inpoed[2 * id + 1] = inpoel[e * 8 + lpoed[t][j][1]];
+    }
+#pragma omp parallel for schedule(dynamic, 65536)
+    for (int64_t q = 0; q < N; ++q) {
+        int64_t h0 = q;                                          // head of this key's group: walk back (groups are short)
+        while (h0 > 0 && (kv[h0 - 1] >> 32) == (kv[q] >> 32)) --h0;
+        const uint64_t first = kv[h0] & 0xffffffffu;
+        const int64_t id = std::lower_bound(by_pos.begin(), by_pos.end(), first) - by_pos.begin();
+        int64_t e; int j;
+        locate((int64_t)(kv[q] & 0xffffffffu), &e, &j);
+        inedel[e * kMaxEdgesPerElement + j] = (int32_t)id;
+    }
     edges_built = true;
 }
 
