@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--method", default="gls", choices=["gls", "idw", "ls"])
     ap.add_argument("--edge", dest="n", type=int, default=216, help="cells per edge per GPU (216^3 = 10,077,696)")
     ap.add_argument("--jitter", type=float, default=0.15)
-    ap.add_argument("--cpu-sample", type=int, default=64, help="edge of the CPU-baseline sample mesh (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=88, help="edge of the CPU-baseline sample mesh (0 = skip)")
     ap.add_argument("--grid-build", default="host", choices=["host", "device"],
                     help="where the Grid connectivity is built (north_star: host, pushed to HBM; device = SURVEY 8 f1)")
     ap.add_argument("--no-other-meshes", action="store_true",
