@@ -1,16 +1,17 @@
 // kernels_gls_group.hip -- GLS weights for homogeneous small-node classes, gfx950: a GROUP of 16 lanes
 // per node (4 nodes per wavefront), the whole least-squares system in registers.
 //
-// Why a second GLS kernel.  kernels_gls.hip maps one node to one wavefront with matrix ROWS across the
-// lanes; every (reflector, column) pair then costs a full cross-lane reduction and the matrix lives in
+// Why a kernel of its own.  The first GLS kernel (kernels_gls.hip) maps one node to one wavefront with matrix ROWS
+// across the lanes; every (reflector, column) pair then costs a full cross-lane reduction and the matrix lives in
 // LDS.  Measured on the 10 M-cell hexahedron mesh (profiles/r01/v1_*): 261 ms, ~60 k issue cycles per
-// node for ~5 k useful FP64 FMAs.  GLS is FP64-ALU-bound, so what matters is FMAs per
+// node for ~5 k useful FP64 FMAs.  (The general kernel of today, kernels_gls_block.hip, keeps the matrix in LDS too.)  GLS is FP64-ALU-bound, so what matters is FMAs per
 // issued instruction.  Here the M x NA matrix of a node is dealt out in 2-D over its 16 lanes:
 //   columns  j -> lane l8 = j % 8, register slot q = j / 8          (3 slots for 24 columns)
 //   rows     r -> half  h  = r % 2, local row     rl = r / 2        (22 local rows for 44 rows)
 // so a lane holds 3 x 22 doubles with compile-time indices (132 VGPRs; VALU can address 256, which is
 // why the rows are split over two lanes instead of 44 rows in one).  A Householder step is then:
-//   * the two owner lanes of column k publish it through LDS,
+//   * the two owner lanes of column k publish it through LDS (from inside step k - 1, right after its update:
+//     look-ahead, see publish()),
 //   * every lane reads back the half it needs and does its part of the norm and of the dot products
 //     with its own columns -- plain FMA chains -- and ONE DPP exchange with the partner half finishes
 //     them; beta / tau are formed redundantly in every lane;
@@ -28,7 +29,8 @@
 // v = (alpha - beta, x): the same H as LAPACK's dlarfg, one division per step instead of two.
 //
 // Eligible nodes (binned on the host, abi.hip): exactly 8 cells and 12 faces, all internal -- every
-// interior node of a hexahedron mesh (M = 44, 24 + 1 columns).  Everything else runs in kernels_gls.hip.
+// interior node of a hexahedron mesh (M = 44, 24 + 1 columns).  Everything else runs in kernels_gls_block.hip.
+// The launch is persistent and XCD-aware (one workgroup per CU, per-XCD work counters): see the kernel body.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
