@@ -24,6 +24,7 @@ UNITS = [
     ("kernels_gls.hip", "hipcc", []),
     ("kernels_gls_block.hip", "hipcc", []),
     ("kernels_gls_group.hip", "hipcc", []),
+    ("kernels_gls_hex8mf.hip", "hipcc", []),
     ("kernels_csr.hip", "hipcc", []),
     # device-side grid build: no contraction, like grid_host.cpp (float32 normals must match the reference)
     ("grid_device.hip", "hipcc", ["-ffp-contract=off"]),

@@ -386,7 +386,10 @@ int nin_grid_to_device(nin_grid *g, int device) {
         const int32_t *lp = nullptr;
         if (d.hex8.count && (rc = dev_upload(d, &lp, hex8_list))) return rc;
         d.hex8.nodes = const_cast<int32_t *>(lp);
-        if (d.hex8.count == P) d.hex8.nodes = nullptr;
+        if (d.hex8.count) {   // lane descriptors of the multifrontal kernel, one 16-byte record per list entry
+            if ((rc = dev_alloc(d, &d.hex8_desc, (size_t)d.hex8.count * 4))) return rc;
+            if (launch_hex8_desc(d.v, d.hex8.nodes, d.hex8.count, d.hex8_desc, nullptr)) return fail(NIN_EHIP, "hex8 descriptor kernel");
+        }
     }
     d.gls_too_large = rows_max[kGlsClasses - 1] > 1024;
     if ((rc = dev_alloc(d, &d.gls_queue, (size_t)kGlsQueueInts))) return rc;
@@ -429,6 +432,15 @@ int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_m
     return NIN_OK;
 }
 
+// cube nodes: the multifrontal kernel (NIN_GLS_HEX8_KERNEL=group: the dense 16-lanes-per-node kernel it replaced,
+// kept for A/B timing)
+static int launch_hex8(DeviceGrid &d, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
+                       double *out, double *nws, hipStream_t stream) {
+    static const bool dense = getenv("NIN_GLS_HEX8_KERNEL") && std::string(getenv("NIN_GLS_HEX8_KERNEL")) == "group";
+    if (dense) return launch_gls_hex8(d.v, nodes, count, add_neumann, out, nws, d.gls_queue, stream);
+    return launch_gls_hex8mf(d.v, nodes, desc, count, add_neumann, out, nws, d.gls_queue, stream);
+}
+
 // one GLS size class: the block kernel with the system in LDS, or the wave kernel on global scratch
 static int launch_class(DeviceGrid &d, int c, const int32_t *nodes, int32_t count, int add_neumann, double *out,
                         double *nws, hipStream_t stream) {
@@ -462,7 +474,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
         else {
             HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
-            rc = launch_gls_hex8(d.v, d.hex8.nodes, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue, stream);
+            rc = launch_hex8(d, d.hex8.nodes, d.hex8_desc, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             for (int c = 0; c < kGlsClasses && !rc; ++c) {
                 rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             }
@@ -493,9 +505,15 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     }
     first[lists.size()] = flat.size();
     int32_t *dl0 = nullptr;
-    HIP_TRY(hipMalloc((void **)&dl0, flat.size() * 4));
+    const size_t n_hex8 = method == NIN_METHOD_GLS ? lists[kGlsClasses].size() : 0;   // + 4 descriptor words per cube node
+    HIP_TRY(hipMalloc((void **)&dl0, (flat.size() + 4 * n_hex8) * 4));
+    int32_t *ddesc = dl0 + flat.size();
     const hipError_t cp = hipMemcpy(dl0, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
     if (cp != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemcpy: %s", hipGetErrorString(cp)); }
+    if (n_hex8 && launch_hex8_desc(d.v, dl0 + first[kGlsClasses], (int32_t)n_hex8, ddesc, stream)) {
+        (void)hipFree(dl0);
+        return fail(NIN_EHIP, "hex8 descriptor kernel");
+    }
     if (method == NIN_METHOD_GLS) {
         const hipError_t qe = hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream);
         if (qe != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemsetAsync: %s", hipGetErrorString(qe)); }
@@ -506,7 +524,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         const int32_t cnt = (int32_t)lists[c].size();
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
-        else if ((int)c == kGlsClasses) rc = launch_gls_hex8(d.v, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue, stream);
+        else if ((int)c == kGlsClasses) rc = launch_hex8(d, dl, ddesc, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else rc = launch_class(d, (int)c, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
     }
     const hipError_t sy = hipStreamSynchronize(stream);   // the lists must outlive the kernels
@@ -639,7 +657,7 @@ int64_t nin_algorithmic_bytes(const nin_grid *g, int method) {
 const char *nin_kernel_name(int method) {
     if (method == NIN_METHOD_IDW) return "nin_rows_kernel<0>";
     if (method == NIN_METHOD_LS) return "nin_rows_kernel<1>";
-    return kernel_name_gls_hex8();   // dominant on hexahedron meshes; kernel_name_gls_block() covers the other nodes
+    return kernel_name_gls_hex8mf();   // dominant on hexahedron meshes; kernel_name_gls_block() covers the other nodes
 }
 
 }  // extern "C"

@@ -77,7 +77,8 @@ struct DeviceGrid {
         int32_t rows_per_lane = 1; // ceil(max rows / 64): the wave kernel of the scratch class
         int32_t max_cells = 0, max_cols = 0, max_rows = 0;
     } gls[kGlsClasses];
-    GlsClass hex8;  // nodes with exactly 8 cells and 12 faces, all internal: kernels_gls_group.hip
+    GlsClass hex8;  // cube nodes (8 cells, 12 internal faces, cube cell graph): kernels_gls_hex8mf.hip
+    int32_t *hex8_desc = nullptr;   // [4 * hex8.count] lane descriptors (hex8_desc.hpp)
     double *gls_scratch = nullptr;  // global-memory systems for the oversize class
     int64_t gls_scratch_stride = 0; // doubles per wave slot
     int32_t gls_scratch_slots = 0;

@@ -26,6 +26,7 @@
 
 #include "device_grid.hpp"
 #include "grid_host.hpp"
+#include "hex8_desc.hpp"
 #include "launch.hpp"
 
 namespace nin {
@@ -558,7 +559,10 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
     const int64_t ne = g.esup_ptr[p + 1] - g.esup_ptr[p], nf = g.fsup_ptr[p + 1] - g.fsup_ptr[p];
     int64_t nbf = 0;
     for (int32_t q = g.fsup_ptr[p]; q < g.fsup_ptr[p + 1]; ++q) nbf += g.face_cells[2 * (int64_t)g.fsup[q] + 1] == -1;
-    if (use_group && ne == 8 && nf == 12 && nbf == 0 && g.dim == 3) { node_class[p] = 255; return; }
+    if (use_group && ne == 8 && nf == 12 && nbf == 0 && g.dim == 3) {
+        int32_t d[4];   // the hex8 kernel needs the cells to form the cube graph (hex8_desc.hpp)
+        if (hex8_descriptor(g, (int32_t)p, d)) { node_class[p] = 255; return; }
+    }
     int64_t bytes, rows, cols;
     const int c = gls_node_class(ne, nf, nbf, force_global != 0, &bytes, &rows, &cols);
     node_class[p] = (uint8_t)c;

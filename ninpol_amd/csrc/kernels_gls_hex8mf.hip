@@ -1,0 +1,471 @@
+// kernels_gls_hex8mf.hip -- GLS weights of "cube" nodes (every interior node of a hexahedron mesh), gfx950:
+// FOUR lanes per node, 16 nodes per wavefront, a multifrontal Householder QR that follows the sparsity of the
+// system instead of sweeping a dense 44 x 24 matrix.
+//
+// The system (gls.pyx:252-356).  Unknowns: a gradient (3 columns) per cell plus the node value (the column c that
+// the last-row identity turns into a right-hand side, see below).  Rows: one per cell -- (x_K - x_v) on its own 3
+// columns, c = 1 -- and three per internal face -- [-B_a | +B_b] on the columns of its two cells, c = 0.  So the
+// cells are the vertices and the faces the edges of a graph, and around an interior hexahedron node that graph is
+// the CUBE: bipartite, 4 "even" cells E0..E3 that share no face, 4 "odd" cells O0..O3 (hex8_desc.hpp fixes the
+// labelling at load time; E_l is adjacent to every odd cell but O_(3-l)).
+//
+// Column order [E0 E1 E2 E3 | O0 O1 O2 O3].  A Householder reflector only touches the rows that are non-zero in its
+// pivot column, so
+//   phase 1  the 12 steps on the even cells' columns are four INDEPENDENT fronts -- the cell row of E_l and the 9
+//            rows of its 3 faces, 10 x (3 own + 12 odd + c) -- one per lane, no cross-lane traffic at all.  Each
+//            leaves 3 rows of R (folded at once into what the weights need of them: z = R_ee^-T d_e, u = z^T R_eo,
+//            s = z . b_e, so R itself is never stored) and 7 filled rows over the 12 odd columns;
+//   phase 2  what is left is 32 x 12: per lane its 7 fill rows and the cell row of O_l, exactly where phase 1 left
+//            them.  Row-distributed Householder: partial dots per lane, one quad reduction (2 DPP stages) per
+//            column and step, pivot rows dealt round-robin (step k: row k / 4 of lane k % 4) so the lanes retire
+//            rows evenly; the scalar chain of a step (beta, 1 / (beta (beta - alpha))) overlaps the partial dots,
+//            which do not need it: v = x - beta e_p differs from x in the pivot lane's pivot entry only, a local fix;
+//   then     R y = Q^T c by columns over the quad, r_i = 1 - d_i . y_i per cell, r . r from the 20 rows left over,
+//            weights r_i / (r . r)  (the identity X[n-1, i] = r_i / (r.r), SURVEY 7.1(i), kernels_gls_group.hip).
+// ~6 k FP64 FMAs per node against ~20 k for the dense sweep, none of them masked out, and no LDS traffic inside
+// the factorisation (the dense kernel published every pivot column through LDS: 22 writes per step).
+// Same mathematics as dgels on the reference's matrix -- a Householder QR, only in a column order that exposes the
+// zeros -- so the weights agree with the reference to rounding (tools/proto_hex8_mf.py: 5e-15 against the oracle).
+//
+// Eligible nodes are binned at load time (k_classify + hex8_desc.hpp): 8 cells, 12 internal faces, cube graph.
+// Everything else runs in kernels_gls_block.hip.  The launch is persistent and XCD-aware (per-XCD work counters),
+// as the dense group kernel's was.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "device_grid.hpp"
+#include "gls_device_math.hpp"
+#include "hex8_desc.hpp"
+#include "launch.hpp"
+
+namespace nin {
+
+namespace {
+
+using namespace glsmath;
+
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+template <int L>
+__device__ __forceinline__ double quad_bcast(double v) { return dpp_mov<L * 0x55>(v); }   // quad_perm [L,L,L,L]
+
+constexpr int NPW = 16;          // nodes per wavefront pass (4 lanes each)
+constexpr int NR = 8, NC = 13;   // phase 2, per lane: 8 rows x (12 odd columns + c)
+
+// Everything a lane reads from HBM for its node, in the order of the dependent chain
+// (list entry -> CSR row starts -> cell / face ids -> geometry and permeability).
+struct Fetch {
+    int32_t p, eb, fb;
+    uint32_t dsc;
+    bool valid;
+    int32_t ce, co, cn[3];
+    size_t f[3];
+    double xv[3], cen_e[3], cen_o[3], Ke[9], dme, fcen[3][3], fn[3][3], Kn[3][9], dmn[3];
+
+    __device__ __forceinline__ void level0(const int32_t *nodes, const int32_t *desc, int32_t idx, int32_t count, int l) {
+        valid = idx < count;
+        const int32_t sel = valid ? idx : count - 1;
+        p = nodes ? nodes[sel] : sel;
+        dsc = (uint32_t)desc[4 * (size_t)sel + l];
+    }
+    __device__ __forceinline__ void level1(const GridView &g) {
+        eb = g.esup_ptr[p];
+        fb = g.fsup_ptr[p];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xv[k] = g.coords[3 * (size_t)p + k];
+    }
+    __device__ __forceinline__ void level2(const GridView &g) {
+        ce = g.esup[eb + (dsc & 7)];
+        co = g.esup[eb + ((dsc >> 3) & 7)];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t w = dsc >> (6 + 8 * i);
+            f[i] = (size_t)g.fsup[fb + (w & 15)];
+            cn[i] = g.esup[eb + ((w >> 4) & 7)];
+        }
+    }
+    __device__ __forceinline__ void level3(const GridView &g) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cen_e[k] = g.centroids[3 * (size_t)ce + k];
+            cen_o[k] = g.centroids[3 * (size_t)co + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ke[k] = g.perm[9 * (size_t)ce + k];
+        dme = g.diff_mag[ce];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                fcen[i][k] = g.face_center[3 * f[i] + k];
+                fn[i][k] = (double)g.face_normal[3 * f[i] + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Kn[i][k] = g.perm[9 * (size_t)cn[i] + k];
+            dmn[i] = g.diff_mag[cn[i]];
+        }
+    }
+};
+
+// Apply the three reflectors of the panel (v_k in P[k..9][k], pivot entries included; g[k]) to W columns of the
+// front.  Z0 / ZA / ZB / ZC: which row groups of the columns can be non-zero on entry (row 0, the rows 1-3, 4-6, 7-9
+// of face 0, 1, 2) -- the others are structural zeros that the first reflector fills.
+template <int W, bool Z0, bool ZA, bool ZB, bool ZC>
+__device__ __forceinline__ void apply_panel(const double (&P)[10][3], const double (&g)[3], double (&B)[10][W]) {
+    double w[W];
+    // reflector 0, rows 0..9
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+        double d = 0.0;
+        if (Z0) d = P[0][0] * B[0][c];
+#pragma unroll
+        for (int r = 1; r < 10; ++r) {
+            const bool nz = (r <= 3) ? ZA : (r <= 6) ? ZB : ZC;
+            if (nz) d = fma(P[r][0], B[r][c], d);
+        }
+        w[c] = -(g[0] * d);
+    }
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const bool nz = (r == 0) ? Z0 : (r <= 3) ? ZA : (r <= 6) ? ZB : ZC;
+#pragma unroll
+        for (int c = 0; c < W; ++c) B[r][c] = nz ? fma(w[c], P[r][0], B[r][c]) : w[c] * P[r][0];
+    }
+    // reflectors 1 and 2, rows k..9 (dense by now)
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            double d = P[k][k] * B[k][c];
+#pragma unroll
+            for (int r = k + 1; r < 10; ++r) d = fma(P[r][k], B[r][c], d);
+            w[c] = -(g[k] * d);
+        }
+#pragma unroll
+        for (int r = k; r < 10; ++r) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) B[r][c] = fma(w[c], P[r][k], B[r][c]);
+        }
+    }
+}
+
+// Phase 2, step K: pivot = local row Q = K / 4 of lane LAM = K % 4.  Local rows < Q are retired in every lane, row
+// Q is retired in the lanes below LAM, active (as a plain row) in the lanes above it.
+template <int K>
+__device__ __forceinline__ void p2_step(double (&C)[NR][NC], double (&rinvq)[3], int l) {
+    constexpr int Q = K / 4, LAM = K % 4;
+    const bool is_piv = (l == LAM);
+    const double mx = (l > LAM) ? 1.0 : 0.0;          // row Q counts as part of x only above the pivot lane
+    const double xq = mx * C[Q][K];
+    // |x|^2 without the pivot entry, and the pivot entry alpha itself
+    double ss = xq * xq;
+#pragma unroll
+    for (int r = Q + 1; r < NR; ++r) ss = fma(C[r][K], C[r][K], ss);
+    // partial dots of x with the live columns: independent of the scalars below, they fill that chain's latency
+    double d[NC];
+#pragma unroll
+    for (int j = K + 1; j < NC; ++j) {
+        double a = xq * C[Q][j];
+#pragma unroll
+        for (int r = Q + 1; r < NR; ++r) a = fma(C[r][K], C[r][j], a);
+        d[j] = a;
+    }
+    ss = quad_sum(ss);
+    const double alpha = quad_bcast<LAM>(C[Q][K]);
+    const House h = house(alpha, ss);
+    rinvq[Q] = is_piv ? h.rinv : rinvq[Q];
+    const double vpl = is_piv ? h.vp : 0.0;           // the pivot entry of v, in the pivot lane only
+    const double vq = is_piv ? h.vp : xq;             // row Q's entry of v in this lane
+#pragma unroll
+    for (int j = K + 1; j < NC; ++j) {
+        const double e = quad_sum(fma(vpl, C[Q][j], d[j]));
+        const double w = -(h.g * e);
+        C[Q][j] = fma(w, vq, C[Q][j]);                // the pivot lane's row Q becomes row K of R
+#pragma unroll
+        for (int r = Q + 1; r < NR; ++r) C[r][j] = fma(w, C[r][K], C[r][j]);
+    }
+}
+
+template <int K, int KEND>
+struct P2Loop {
+    static __device__ __forceinline__ void run(double (&C)[NR][NC], double (&rinvq)[3], int l) {
+        p2_step<K>(C, rinvq, l);
+        P2Loop<K + 1, KEND>::run(C, rinvq, l);
+    }
+};
+template <int KEND>
+struct P2Loop<KEND, KEND> {
+    static __device__ __forceinline__ void run(double (&)[NR][NC], double (&)[3], int) {}
+};
+
+// Back-substitution of the odd unknowns by columns: row K of R lives in lane K % 4, local row K / 4 (entries
+// C[Q][j], j > K, right-hand side t[Q]).  y_K is formed in its lane and broadcast; every lane then takes
+// R(K', K) y_K off the right-hand sides of its own rows K' < K.
+template <int K>
+struct BackLoop {
+    static __device__ __forceinline__ void run(const double (&C)[NR][NC], const double (&rinvq)[3], double (&t)[3],
+                                               double (&y)[12], int l) {
+        constexpr int Q = K / 4, LAM = K % 4;
+        const double yk = quad_bcast<LAM>(t[Q] * rinvq[Q]);
+        y[K] = yk;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) t[q] = fma(-C[q][K], yk, t[q]);          // rows 4 q + l < K in every lane
+        if (LAM > 0) t[Q] = fma((l < LAM) ? -C[Q][K] : 0.0, yk, t[Q]);       // row 4 Q + l < K only below the pivot lane
+        BackLoop<K - 1>::run(C, rinvq, t, y, l);
+    }
+};
+template <>
+struct BackLoop<-1> {
+    static __device__ __forceinline__ void run(const double (&)[NR][NC], const double (&)[3], double (&)[3], double (&)[12], int) {}
+};
+
+__global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, const int32_t *__restrict__ nodes,
+                                                                const int32_t *__restrict__ desc, int32_t count,
+                                                                int add_neumann, double *__restrict__ out,
+                                                                double *__restrict__ nws, int32_t *__restrict__ queue) {
+    __shared__ double wbuf_all[4][NPW * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane & 3, nd = lane >> 2;
+    double *wbuf = wbuf_all[wave];
+
+    const int32_t n_groups = (count + NPW - 1) / NPW;
+    // XCD x walks the x-th contiguous eighth of the node list; its waves pull consecutive 16-node groups off a
+    // per-XCD counter (neighbouring mesh rows meet in one L2 a few passes apart, late CUs take fewer groups)
+    int32_t wg_lo, wg_end;
+    int32_t *q;
+    if ((gridDim.x & 7) == 0) {
+        const int32_t xcd = blockIdx.x & 7, per = (n_groups + 7) / 8;
+        wg_lo = xcd * per;
+        wg_end = (xcd + 1) * per < n_groups ? (xcd + 1) * per : n_groups;
+        q = queue + 16 * xcd;   // one counter per 64-byte line
+    } else {
+        wg_lo = 0;
+        wg_end = n_groups;
+        q = queue;
+    }
+    auto grab = [&]() -> int32_t {
+        int32_t v = 0;
+        if (lane == 0) v = atomicAdd(q, 1);
+        return wg_lo + __builtin_amdgcn_readfirstlane(v);
+    };
+    // lane-role masks (as multipliers): face i of lane l sits on odd slot i (i < 3 - l) or i + 1
+    const double mA0 = (l != 3) ? 1.0 : 0.0, mA1 = (l < 2) ? 1.0 : 0.0, mA2 = (l == 0) ? 1.0 : 0.0;
+    const double mB1 = (l == 3) ? 1.0 : 0.0, mB2 = (l >= 2) ? 1.0 : 0.0, mB3 = (l != 0) ? 1.0 : 0.0;
+
+    Fetch cur;
+    int32_t wg = grab();
+    while (wg < wg_end) {
+        cur.level0(nodes, desc, wg * NPW + nd, count, l);
+        wg = grab();
+        cur.level1(g);
+        cur.level2(g);
+        cur.level3(g);
+        const bool valid = cur.valid;
+        const int32_t p = cur.p, eb = cur.eb;
+        const uint32_t dsc = cur.dsc;
+
+        // ---- the front of E_l: rows 0 = cell row, 1 + 3 i + r = row r of face i; own columns in P ------------
+        double P[10][3], de[3], dod[3], nb0[3][3];   // nb0[i] = first row of the neighbour-side block of face i
+        {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                de[t] = cur.cen_e[t] - cur.xv[t];      // gls.pyx:269-277
+                dod[t] = cur.cen_o[t] - cur.xv[t];
+                P[0][t] = de[t];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                // B = [K N; T1; tau T2] (gls.pyx:293-321), row = [-B_a | +B_b] (gls.pyx:340-356)
+                const double N0 = cur.fn[i][0], N1 = cur.fn[i][1], N2 = cur.fn[i][2];
+                const double T0 = cur.xv[0] - cur.fcen[i][0], T1 = cur.xv[1] - cur.fcen[i][1], T2 = cur.xv[2] - cur.fcen[i][2];
+                const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+                double eta = 0.0;
+                eta = cur.dme > eta ? cur.dme : eta;
+                eta = cur.dmn[i] > eta ? cur.dmn[i] : eta;
+                const double un = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
+                const double tj = face_tau(un, eta);
+                const bool side_a = ((dsc >> (6 + 8 * i + 7)) & 1) != 0;
+                const double sg = side_a ? -1.0 : 1.0;
+                const double *Ke = cur.Ke, *Kn = cur.Kn[i];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    P[1 + 3 * i][t] = sg * (Ke[t * 3 + 0] * N0 + Ke[t * 3 + 1] * N1 + Ke[t * 3 + 2] * N2);
+                    nb0[i][t] = -sg * (Kn[t * 3 + 0] * N0 + Kn[t * 3 + 1] * N1 + Kn[t * 3 + 2] * N2);
+                }
+                P[2 + 3 * i][0] = sg * T0; P[2 + 3 * i][1] = sg * T1; P[2 + 3 * i][2] = sg * T2;
+                P[3 + 3 * i][0] = sg * (tj * U0); P[3 + 3 * i][1] = sg * (tj * U1); P[3 + 3 * i][2] = sg * (tj * U2);
+            }
+        }
+        // ---- the odd-slot blocks of the front, before the panel overwrites the face rows it shares with them -------
+        // slot s takes face s (lanes with s < 3 - l) or face s - 1 (s > 3 - l); rows 1, 2 of a neighbour block are
+        // minus the own block's
+        double C[NR][NC];
+        double u[12], se;
+        double g3[3], rinv[3], z[3];
+        {
+            double B0[10][3], B1[10][3], B2[10][3], B3[10][3], Bc[10][1];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                B0[1][t] = mA0 * nb0[0][t]; B0[2][t] = -(mA0 * P[2][t]); B0[3][t] = -(mA0 * P[3][t]);
+                B1[1][t] = mB1 * nb0[0][t]; B1[2][t] = -(mB1 * P[2][t]); B1[3][t] = -(mB1 * P[3][t]);
+                B1[4][t] = mA1 * nb0[1][t]; B1[5][t] = -(mA1 * P[5][t]); B1[6][t] = -(mA1 * P[6][t]);
+                B2[4][t] = mB2 * nb0[1][t]; B2[5][t] = -(mB2 * P[5][t]); B2[6][t] = -(mB2 * P[6][t]);
+                B2[7][t] = mA2 * nb0[2][t]; B2[8][t] = -(mA2 * P[8][t]); B2[9][t] = -(mA2 * P[9][t]);
+                B3[7][t] = mB3 * nb0[2][t]; B3[8][t] = -(mB3 * P[8][t]); B3[9][t] = -(mB3 * P[9][t]);
+            }
+            // ---- panel: three Householder steps on the own columns; v_k stays in P[k..9][k] ----------------------
+            {
+                double ss = 0.0;
+#pragma unroll
+                for (int r = 1; r < 10; ++r) ss = fma(P[r][0], P[r][0], ss);
+                const House h = house(P[0][0], ss);
+                g3[0] = h.g; rinv[0] = h.rinv;
+                double d1 = h.vp * P[0][1], d2 = h.vp * P[0][2];
+#pragma unroll
+                for (int r = 1; r < 10; ++r) { d1 = fma(P[r][0], P[r][1], d1); d2 = fma(P[r][0], P[r][2], d2); }
+                const double w1 = -(h.g * d1), w2 = -(h.g * d2);
+                P[0][0] = h.vp;
+#pragma unroll
+                for (int r = 0; r < 10; ++r) { P[r][1] = fma(w1, P[r][0], P[r][1]); P[r][2] = fma(w2, P[r][0], P[r][2]); }
+            }
+            {
+                double ss = 0.0;
+#pragma unroll
+                for (int r = 2; r < 10; ++r) ss = fma(P[r][1], P[r][1], ss);
+                const House h = house(P[1][1], ss);
+                g3[1] = h.g; rinv[1] = h.rinv;
+                double d2 = h.vp * P[1][2];
+#pragma unroll
+                for (int r = 2; r < 10; ++r) d2 = fma(P[r][1], P[r][2], d2);
+                const double w2 = -(h.g * d2);
+                P[1][1] = h.vp;
+#pragma unroll
+                for (int r = 1; r < 10; ++r) P[r][2] = fma(w2, P[r][1], P[r][2]);
+            }
+            {
+                double ss = 0.0;
+#pragma unroll
+                for (int r = 3; r < 10; ++r) ss = fma(P[r][2], P[r][2], ss);
+                const House h = house(P[2][2], ss);
+                g3[2] = h.g; rinv[2] = h.rinv;
+                P[2][2] = h.vp;
+            }
+            // z = R_ee^-T d_e: all the weights need of the even cell's three rows of R
+            z[0] = de[0] * rinv[0];
+            z[1] = fma(-P[0][1], z[0], de[1]) * rinv[1];
+            z[2] = fma(-P[1][2], z[1], fma(-P[0][2], z[0], de[2])) * rinv[2];
+            // ---- the reflectors on the odd-slot blocks and on c ---------------------------------------------------
+            apply_panel<3, false, true, false, false>(P, g3, B0);
+            apply_panel<3, false, true, true, false>(P, g3, B1);
+            apply_panel<3, false, false, true, true>(P, g3, B2);
+            apply_panel<3, false, false, false, true>(P, g3, B3);
+            Bc[0][0] = 1.0;                                   // c = e_0 on entry: only the cell row carries a 1
+            apply_panel<1, true, false, false, false>(P, g3, Bc);
+            // rows 0..2 -> u = z^T R_eo and s = z . b_e;  rows 3..9 -> this lane's rows 0..6 of the 32 x 12 problem
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                u[t] = fma(z[2], B0[2][t], fma(z[1], B0[1][t], z[0] * B0[0][t]));
+                u[3 + t] = fma(z[2], B1[2][t], fma(z[1], B1[1][t], z[0] * B1[0][t]));
+                u[6 + t] = fma(z[2], B2[2][t], fma(z[1], B2[1][t], z[0] * B2[0][t]));
+                u[9 + t] = fma(z[2], B3[2][t], fma(z[1], B3[1][t], z[0] * B3[0][t]));
+            }
+            se = fma(z[2], Bc[2][0], fma(z[1], Bc[1][0], z[0] * Bc[0][0]));
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    C[r][t] = B0[3 + r][t];
+                    C[r][3 + t] = B1[3 + r][t];
+                    C[r][6 + t] = B2[3 + r][t];
+                    C[r][9 + t] = B3[3 + r][t];
+                }
+                C[r][12] = Bc[3 + r][0];
+            }
+        }
+        // row 7: the cell row of O_l, (x_K - x_v) on the columns of odd slot l, c = 1
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double ms = (l == s) ? 1.0 : 0.0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) C[7][3 * s + t] = ms * dod[t];
+        }
+        C[7][12] = 1.0;
+
+        // ---- phase 2: 32 x 12 over the quad ------------------------------------------------------------------
+        double rinvq[3] = {0.0, 0.0, 0.0};
+        P2Loop<0, 12>::run(C, rinvq, l);
+        double y[12], t3[3] = {C[0][12], C[1][12], C[2][12]};
+        BackLoop<11>::run(C, rinvq, t3, y, l);
+        double tail = 0.0;
+#pragma unroll
+        for (int r = 3; r < NR; ++r) tail = fma(C[r][12], C[r][12], tail);
+        const double rr = quad_sum(tail);                        // r . r = |(Q^T c)(24:44)|^2
+
+        // ---- residuals on the two cell rows of this lane, weights ----------------------------------------------
+        double re = 1.0 - se;                                    // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_odd
+#pragma unroll
+        for (int j = 0; j < 12; ++j) re = fma(u[j], y[j], re);
+        double dots[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dots[s] = fma(dod[2], y[3 * s + 2], fma(dod[1], y[3 * s + 1], dod[0] * y[3 * s]));
+        const double dsel = (l == 0) ? dots[0] : (l == 1) ? dots[1] : (l == 2) ? dots[2] : dots[3];
+        const double ro = 1.0 - dsel;
+        double we = re / rr, wo = ro / rr;
+        const bool ok = rr > 0.0;                                // rank-deficient system: undefined in the reference, 0 here
+        we = (ok && we - we == 0.0) ? we : 0.0;
+        wo = (ok && wo - wo == 0.0) ? wo : 0.0;
+
+        // ---- out: the node's 8 weights in esup order, written as 16-byte pieces ---------------------------------
+        wbuf[nd * 8 + (dsc & 7)] = we;
+        wbuf[nd * 8 + ((dsc >> 3) & 7)] = wo;
+        wave_lds_sync();
+        const bool is_neu = (g.flags[p] & 2) != 0;
+        // gls.pyx:470-472 (only if an interior node carries the Neumann flag): neumann_ws = the last cell's weight
+        const double nwv = is_neu ? wbuf[nd * 8 + 7] : 0.0;
+        const double addv = add_neumann ? nwv : 0.0;
+        const double o0 = wbuf[nd * 8 + 2 * l] + addv, o1 = wbuf[nd * 8 + 2 * l + 1] + addv;
+        if (valid) {
+            out[eb + 2 * l] = o0;
+            out[eb + 2 * l + 1] = o1;
+            if (l == 0) nws[p] = nwv;
+        }
+        wave_lds_sync();
+    }
+}
+
+__global__ void k_hex8_desc(GridView g, const int32_t *__restrict__ nodes, int32_t count, int32_t *__restrict__ desc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    int32_t d[4] = {0, 0, 0, 0};
+    (void)hex8_descriptor(g, nodes ? nodes[i] : (int32_t)i, d);   // the list holds classified cube nodes only
+#pragma unroll
+    for (int l = 0; l < 4; ++l) desc[4 * i + l] = d[l];
+}
+
+}  // namespace
+
+int launch_hex8_desc(const GridView &g, const int32_t *nodes, int32_t count, int32_t *desc, hipStream_t stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_hex8_desc, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, g, nodes, count, desc);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
+                      double *out, double *nws, int32_t *queue, hipStream_t stream) {
+    if (count <= 0) return 0;
+    int64_t blocks = ((int64_t)count + 4 * NPW - 1) / (4 * NPW);
+    const int64_t cap = 256;   // 512 registers per lane: one 4-wave workgroup per CU is resident; persistent, blockIdx % 8 = XCD
+    if (blocks > cap) blocks = cap;
+    if (blocks > 8) blocks &= ~(int64_t)7;
+    hipLaunchKernelGGL(nin_gls_hex8mf_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count,
+                       add_neumann, out, nws, queue);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+const char *kernel_name_gls_hex8mf() { return "nin_gls_hex8mf_kernel"; }
+
+}  // namespace nin

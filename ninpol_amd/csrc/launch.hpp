@@ -28,6 +28,12 @@ const char *kernel_name_gls_block();
 int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out,
                     double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_hex8();
+// the multifrontal kernel for cube nodes (kernels_gls_hex8mf.hip): 4 lanes per node; `desc` = 4 descriptor words per
+// list entry (hex8_desc.hpp, filled by launch_hex8_desc); `queue` as above
+int launch_hex8_desc(const GridView &g, const int32_t *nodes, int32_t count, int32_t *desc, hipStream_t stream);
+int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
+                      double *out, double *nws, int32_t *queue, hipStream_t stream);
+const char *kernel_name_gls_hex8mf();
 // out[j] += nws[row(j)] for IDW / LS is a no-op (their neumann_ws is 0): nothing to launch.
 
 // CSR finish (interpolator.pyx:622-624): count non-zeros per row, scan, compact

@@ -23,7 +23,9 @@ Finally `oracle/ninpol_ref_driver.pyx` (OUR code) is compiled against the refere
 exposes `build_grid(...)` and `run_method(...)` to Python so tests can drive the real `Grid` and the
 real `prepare()` plugins, which are `cdef` and otherwise unreachable without `Interpolator`.
 
-Outputs go only to oracle/_ref/ (git-ignored, but shipped to the GPU box by gpurun).
+Outputs go only to oracle/_ref/, which is git-ignored AND listed in .gpurunignore: the compiled reference is a
+dev-container tool (validating the C restatement, generating tests/golden, the CPU calibration in
+profiles/cpu_calibration.json) and never travels to the GPU box.
 """
 import os
 import subprocess
@@ -87,7 +89,7 @@ def build(force=False):
     """Build oracle/_ref if the reference tree is present. Returns True when _ref is usable."""
     driver_so = os.path.join(OUT, "ninpol_ref_driver" + ext_suffix())
     if not os.path.isdir(os.path.join(REF, "ninpol")):
-        return os.path.exists(driver_so)        # GPU box: use the prebuilt files, if any
+        return False                            # no reference tree (the GPU box): nothing to build, nothing to use
     if os.path.exists(driver_so) and not force:
         newest_src = max(os.path.getmtime(p) for p in
                          [os.path.join(HERE, "ninpol_ref_driver.pyx"), os.path.abspath(__file__)])

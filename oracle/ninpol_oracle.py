@@ -77,10 +77,16 @@ def _lib():
     return _LIB
 
 
+REFERENCE_TREE = os.environ.get("NINPOL_REFERENCE", "/root/reference")
+
+
 def have_reference():
-    """True when oracle/_ref holds the compiled reference (built here, shipped to the GPU box)."""
+    """True only in the dev container: oracle/_ref holds the compiled reference AND the reference tree it was
+    built from is mounted.  oracle/_ref is listed in .gpurunignore -- the reference never travels to the GPU box
+    in any form -- and the second condition keeps this False there even if it did."""
     suffix = sysconfig.get_config_var("EXT_SUFFIX")
-    return os.path.exists(os.path.join(HERE, "_ref", "ninpol_ref_driver" + suffix))
+    return (os.path.isdir(os.path.join(REFERENCE_TREE, "ninpol"))
+            and os.path.exists(os.path.join(HERE, "_ref", "ninpol_ref_driver" + suffix)))
 
 
 def _ref_driver():
