@@ -14,19 +14,25 @@ With N GPUs the box grows to 216 x 216 x 216 N cells (weak scaling): rank r owns
 node planes, replicates one cell layer on each interior side, and no rank ever holds the whole mesh.
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
-  roofline      HBM roofline of the dominant kernel: algorithmic bytes (SURVEY 8d formula) / the kernel's
-                average duration measured with HIP events on the launch stream; `traffic` from
-                profiles/traffic.json when a PMC run has been recorded, else null
-  cpu_baseline  the reference's own GLS (oracle/_ref, kind "reference") -- or our C restatement
-                ("port") when _ref is absent -- timed on this box's host cores on a bounded sample
-  fp64          GLS is FP64-ALU-bound, not HBM-bound, in the reference formulation (SURVEY finding 2):
-                achieved reference-equivalent FLOP/s next to the 78.6 TFLOP/s vector peak.
+  roofline      of the dominant kernel, duration measured with HIP events on the launch stream.  GLS: bound "fp64"
+                (executed flops / time against the FP64 vector peak) with the HBM figure -- algorithmic bytes of
+                SURVEY 8d / time against 8 TB/s -- as `hbm` / `hbm_frac`; IDW, LS: bound "hbm".  `traffic` from
+                profiles/traffic.json when a PMC run of exactly these kernel sources has been recorded, else null
+  cpu_baseline  our C restatement of the reference's method kernel (kind "port"; the reference itself never
+                travels to the GPU box) timed on this box's host cores on a bounded sample, with the container-measured
+                t_port / t_reference calibration beside it
+  fp64          GLS is FP64-ALU-bound, not HBM-bound (SURVEY finding 2): executed and reference-equivalent
+                FLOP/s next to the 78.6 TFLOP/s vector peak.
+  baseline_configs  one row per single-GPU entry of BASELINE.json's `configs`.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
+
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")   # before anything loads numpy / scipy (OpenBLAS reads it at load)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -34,32 +40,71 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6     # vector FP64
 REF_FLOPS_PER_NODE_HEX = 74.8e3   # dgels 44 x 25 x 8 per interior hexahedron node
+# FP64 operations the multifrontal kernel EXECUTES per interior hexahedron node (fma = 2, mul / add = 1, the 4 lanes
+# of a node summed), counted on the kernel's ISA by tools/count_fp64.py (profiles/r02/hex8mf_isa_mix.txt)
+EXEC_FLOPS_PER_NODE_HEX = 20.5e3
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: stamps profiles/traffic.json, so a stale PMC figure is never reported."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ninpol_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(method, n_sample, jitter):
-    """Time the CPU path on a bounded sample: the same mesh recipe at n_sample^3 cells."""
+    """The CPU number beside the GPU one: our C restatement of the reference's method kernel (oracle/ninpol_oracle.c,
+    kind "port" -- the reference's Cython never travels to the GPU box) on a bounded sample: the same mesh
+    recipe at n_sample^3 cells.  Two runs: min(16, cores) OpenMP threads as gls.pyx:87 / idw.pyx:55 schedule it, and
+    all cores.  `calibration` is t_port / t_reference measured in the dev container (tools/cpu_calibration.py)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
     import ninpol_oracle as O
     from ninpol_amd import mesh as M
-    kind = "reference" if O.have_reference() else "port"
-    try:
-        o = O.OracleInterpolator(kind)
-    except Exception:
-        kind = "port"
-        o = O.OracleInterpolator(kind)
-    cores = min(16, os.cpu_count() or 1)   # gls.pyx:87 hard-codes 16 OpenMP threads
-    o.threads = cores
+    ncpu = os.cpu_count() or 1
+    cores = min(16, ncpu)
     m = M.hex_mesh(n_sample, jitter=jitter, seed=0)
     M.attach_fields(m, "u", perm="ALH")
+    o = O.OracleInterpolator("port", threads=cores)
     o.load_mesh(m)
-    t0 = time.time()
-    o.prepare(method, "u")
-    dt = time.time() - t0
     P = o.grid.n_points
-    return {"value": round(P / dt / 1e6, 4), "unit": "Mnodes/s", "cores": cores, "kind": kind,
-            "sample": f"{method.upper()} prepare() on a {n_sample}^3-cell hex mesh of the same recipe "
-                      f"({P} nodes, {dt:.2f} s, method kernel only)"}
+    dt = 1e30
+    for _ in range(3):   # best of three: ~10 s of host work at the default 128^3 sample
+        t0 = time.time()
+        o.prepare(method, "u")
+        dt = min(dt, time.time() - t0)
+    out = {"value": round(P / dt / 1e6, 4), "unit": "Mnodes/s", "cores": cores, "kind": "port",
+           "sample": f"{method.upper()} method kernel (C restatement of the reference, OpenMP) on a {n_sample}^3-cell hex "
+                     f"mesh of the same recipe ({P} nodes, best of 3: {dt:.2f} s)",
+           "cpu_model": cpu_model(), "logical_cpus": ncpu, "OMP_threads": cores, "OPENBLAS_NUM_THREADS": "1 (unused by the port)"}
+    if ncpu > cores:
+        o.threads = ncpu
+        t0 = time.time()
+        o.prepare(method, "u")
+        dt2 = time.time() - t0
+        out["all_cores"] = {"value": round(P / dt2 / 1e6, 4), "cores": ncpu, "seconds": round(dt2, 2)}
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "cpu_calibration.json")))
+        r = cal[f"{method}_t_port_over_t_ref"]
+        out["calibration"] = {"t_port_over_t_ref": r, "reference_equivalent_value": round(out["value"] * r, 4),
+                              "measured_on": f"{cal['cpu_model']} ({cal['threads']} threads, dev container, "
+                                             "tools/cpu_calibration.py)"}
+    except Exception:
+        out["calibration"] = None
+    return out
 
 
 def main():
@@ -70,7 +115,7 @@ def main():
     ap.add_argument("--method", default="gls", choices=["gls", "idw", "ls"])
     ap.add_argument("--edge", dest="n", type=int, default=216, help="cells per edge per GPU (216^3 = 10,077,696)")
     ap.add_argument("--jitter", type=float, default=0.15)
-    ap.add_argument("--cpu-sample", type=int, default=88, help="edge of the CPU-baseline sample mesh (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="edge of the CPU-baseline sample mesh (0 = skip)")
     ap.add_argument("--grid-build", default="host", choices=["host", "device"],
                     help="where the Grid connectivity is built (north_star: host, pushed to HBM; device = SURVEY 8 f1)")
     ap.add_argument("--no-other-meshes", action="store_true",
@@ -261,13 +306,27 @@ def main():
         value = total_nodes * args.steps / elapsed / 1e6
         B_alg = plan.algorithmic_bytes
         ach = B_alg / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = None   # PMC bytes per launch, only if recorded for exactly these kernel sources
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{args.method}_n{n}_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("kernel_source_sha16") == kernel_source_hash():
+                    traffic = tj.get(f"{args.method}_n{n}_bytes_per_launch")
             except Exception:
                 traffic = None
+        hbm = {"achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
+        if args.method == "gls":
+            # GLS is FP64-ALU-bound, not HBM-bound (SURVEY finding 2): the roofline of record is the FP64 vector peak,
+            # priced on the flops the kernel EXECUTES; the HBM fraction (BASELINE's metric) rides beside it
+            ex = EXEC_FLOPS_PER_NODE_HEX * P_loc / (kern_ms * 1e-3) / 1e12
+            roof = {"bound": "fp64", "achieved": round(ex, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ex / FP64_PEAK_TFLOPS, 4), "executed_flops_per_node": EXEC_FLOPS_PER_NODE_HEX,
+                    "hbm": hbm, "hbm_frac": hbm["frac"]}
+        else:
+            roof = dict(hbm, bound="hbm")
+        roof.update({"traffic": traffic, "kernel": plan.kernel_name, "kernel_ms": round(kern_ms, 4),
+                     "algorithmic_bytes_per_launch": B_alg, "bytes_per_node": round(B_alg / P_loc, 1)})
         line = {
             "metric": "Mnodes/s interpolated (GLS, 10M-cell hex mesh) + achieved HBM GB/s vs peak"
                       if args.method == "gls" and n == 216 else f"Mnodes/s interpolated ({args.method.upper()}, {n}^3-cell hex mesh per GPU)",
@@ -281,10 +340,7 @@ def main():
                                       "step's kernel (two output buffers)" if world > 1 else ""),
                        "cells_per_gpu": n ** 3, "nodes_total": total_nodes, "nnz_esup_rank0": plan.nnz,
                        "parallelism": f"node-block shards x{world}, neighbour cells replicated" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": plan.kernel_name, "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": B_alg, "bytes_per_node": round(B_alg / P_loc, 1)},
+            "roofline": roof,
             "setup_s": {"mesh_gen": round(t_gen, 2), "load_mesh": round(t_load, 2), "push_to_hbm": round(t_push, 2),
                         "grid_build": args.grid_build},
         }
@@ -297,8 +353,10 @@ def main():
         if args.method == "gls":
             flops = REF_FLOPS_PER_NODE_HEX * P_loc / (kern_ms * 1e-3) / 1e12
             line["fp64"] = {"ref_equiv_tflops": round(flops, 3), "peak_tflops": FP64_PEAK_TFLOPS,
-                            "frac": round(flops / FP64_PEAK_TFLOPS, 4),
-                            "note": "74.8 kflop/node = dgels 44x25x8 of the reference; GLS is FP64-bound (SURVEY finding 2)"}
+                            "ref_equiv_frac": round(flops / FP64_PEAK_TFLOPS, 4),
+                            "executed_tflops": roof["achieved"], "executed_frac": roof["frac"],
+                            "note": "ref_equiv prices the node rate at the reference's dense dgels 44x25x8 = 74.8 kflop/node "
+                                    "(SURVEY 8d); the multifrontal kernel executes ~20.5 kflop/node, so ref_equiv may pass 1"}
         if world == 1 and not args.no_extras:
             # context: the two HBM-bound methods on the same grid, and end-to-end interpolate()
             for meth in ("idw", "ls"):
@@ -324,30 +382,41 @@ def main():
             line["e2e_interpolate_s"] = round(time.time() - t0, 3)
             line["e2e_nnz"] = int(W.nnz)
             del W, I
-            # context: GLS on the other mesh families of BASELINE.json's configs (block kernel)
+            # one row per single-GPU entry of BASELINE.json's `configs` (kernel only, HIP events): [1] IDW and
+            # [2] GLS on the 1 M-cell hexahedron mesh, [3] GLS on the 10 M-cell hex | pyramid | tet mix; plus the Kuhn-tet
+            # mesh the block kernel is tuned on.  ([0] is the reference's CPU plumbing case, [4] the 8-GPU run: --gpus 8.)
             if args.method == "gls" and not args.no_other_meshes:
-                other = {}
-                for name, make in (("kuhn_tets_40^3", lambda: M.tet_mesh(40, jitter=0.1)),
-                                   ("hex_pyramid_tet_mix_100x60x60", lambda: M.mixed_mesh(100, 60, 60, jitter=0.1))):
-                    mo = make()
-                    M.attach_fields(mo, "u", perm="ALH")
-                    Io = ninpol_amd.Interpolator(device=local_rank, grid_build="device")
-                    Io.load_mesh(mesh_obj=mo)
-                    po = Io.device_plan("u", "gls")
+                def timed(Io, meth, reps=3):
+                    po = Io.device_plan("u", meth)
                     oo = torch.empty(po.nnz, dtype=torch.float64, device=dev)
                     no = torch.empty(po.n_points, dtype=torch.float64, device=dev)
                     po.launch(oo.data_ptr(), no.data_ptr(), stream.cuda_stream)
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(stream)
-                    for _ in range(3):
+                    for _ in range(reps):
                         po.launch(oo.data_ptr(), no.data_ptr(), stream.cuda_stream)
                     b.record(stream)
                     torch.cuda.synchronize()
-                    ms = a.elapsed_time(b) / 3
-                    other[name] = {"cells": int(Io.grid.n_elems), "nodes": int(Io.grid.n_points), "kernel_ms": round(ms, 3),
-                                   "Mnodes_per_s": round(Io.grid.n_points / ms / 1e3, 2)}
-                    del Io, po, oo, no, mo
-                line["gls_other_meshes"] = other
+                    ms = a.elapsed_time(b) / reps
+                    gb = po.algorithmic_bytes / (ms * 1e-3) / 1e9
+                    return {"kernel_ms": round(ms, 3), "Mnodes_per_s": round(Io.grid.n_points / ms / 1e3, 2),
+                            "achieved_GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBS, 4)}
+                rows = {}
+                for name, make, meths in (
+                        ("[1],[2] hex 100^3", lambda: M.hex_mesh(100, jitter=args.jitter), ("idw", "gls")),
+                        ("[3] hex|pyramid|tet mix 200x120x120", lambda: M.mixed_mesh(200, 120, 120, jitter=0.1), ("gls",)),
+                        ("kuhn tets 40^3", lambda: M.tet_mesh(40, jitter=0.1), ("gls",))):
+                    mo = make()
+                    M.attach_fields(mo, "u", perm="ALH")
+                    Io = ninpol_amd.Interpolator(device=local_rank, grid_build="device")
+                    Io.load_mesh(mesh_obj=mo)
+                    row = {"cells": int(Io.grid.n_elems), "nodes": int(Io.grid.n_points)}
+                    for meth in meths:
+                        row[meth] = timed(Io, meth)
+                    rows[name] = row
+                    del Io, mo
+                    torch.cuda.empty_cache()
+                line["baseline_configs"] = rows
         if world == 1 and args.cpu_sample > 0:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.method, args.cpu_sample, args.jitter)

@@ -56,39 +56,93 @@ __device__ __forceinline__ double quad_bcast(double v) { return dpp_mov<L * 0x55
 constexpr int NPW = 16;          // nodes per wavefront pass (4 lanes each)
 constexpr int NR = 8, NC = 13;   // phase 2, per lane: 8 rows x (12 odd columns + c)
 
+// Loads whose results are not looked at before a later point of the pass, written so that they STAY where they are
+// put: the destination is an accumulation register named in the instruction itself (a value the register allocator
+// parks in an AGPR on its own gets there through a VGPR copy -- i.e. a full wait right behind the load -- and plain
+// loads get sunk to their first use, a pass later).  The compiler does not know these are in flight: every consumer
+// goes through settle(), an s_waitcnt vmcnt(0) that takes the values in and hands them out again.  Its own waits stay
+// correct with unknown loads in flight, only more conservative (vmcnt counts in order); the one place it waits, for
+// the geometry at the top of a pass, comes before any of these is issued.
+__device__ __forceinline__ uint32_t lazy_u32(const void *ptr) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=a"(v) : "v"(ptr) : "memory");
+    return v;
+}
+// the same, held behind the computation of `after` by a data dependence (pure arithmetic may otherwise sink below it)
+__device__ __forceinline__ uint32_t lazy_u32_after(const void *ptr, double after) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=a"(v) : "v"(ptr), "v"(after) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t lazy_u8(const void *ptr) {
+    uint32_t v;
+    asm volatile("global_load_ubyte %0, %1, off" : "=a"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ double lazy_f64(const void *ptr) {
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(v) : "v"(ptr) : "memory");
+    return v;
+}
+// returning atomic add of 1 (one lane): the work-queue ticket
+__device__ __forceinline__ uint32_t lazy_ticket(int32_t *ptr) {
+    uint32_t v, one = 1;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=a"(v) : "v"(ptr), "a"(one) : "memory");
+    return v;
+}
+__device__ __forceinline__ void settle(uint32_t &a, uint32_t &b, uint32_t &c) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+a"(a), "+a"(b), "+a"(c) : : "memory");
+}
+__device__ __forceinline__ void settle(uint32_t &a, uint32_t &b, uint32_t &c, double &x, double &y, double &z) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+a"(a), "+a"(b), "+a"(c), "+a"(x), "+a"(y), "+a"(z) : : "memory");
+}
+__device__ __forceinline__ void settle(uint32_t (&a)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]), "+a"(a[6]), "+a"(a[7])
+                 :
+                 : "memory");
+}
+
 // Everything a lane reads from HBM for its node, in the order of the dependent chain
-// (list entry -> CSR row starts -> cell / face ids -> geometry and permeability).
+// (work ticket, list entry -> CSR row starts -> cell / face ids -> geometry and permeability).
 struct Fetch {
-    int32_t p, eb, fb;
-    uint32_t dsc;
+    uint32_t p, dsc, eb, fb, flag;   // (ids unsigned: widening them for the address arithmetic is free)
+    uint32_t ticket;                 // the work-queue value read alongside level 0 (lane 0 only)
     bool valid;
-    int32_t ce, co, cn[3];
-    size_t f[3];
+    uint32_t id[8];                  // ce, co, cn[0..2], f[0..2]
     double xv[3], cen_e[3], cen_o[3], Ke[9], dme, fcen[3][3], fn[3][3], Kn[3][9], dmn[3];
 
-    __device__ __forceinline__ void level0(const int32_t *nodes, const int32_t *desc, int32_t idx, int32_t count, int l) {
+    __device__ __forceinline__ void level0(const int32_t *nodes, const int32_t *desc, int32_t idx, int32_t count, int l,
+                                           int32_t *queue, bool leader, double after) {
         valid = idx < count;
-        const int32_t sel = valid ? idx : count - 1;
-        p = nodes ? nodes[sel] : sel;
-        dsc = (uint32_t)desc[4 * (size_t)sel + l];
+        const uint32_t sel = (uint32_t)(valid ? idx : count - 1);   // past the end: a clamped (valid) entry, never stored
+        p = lazy_u32_after(nodes + sel, after);
+        dsc = lazy_u32(desc + 4 * (size_t)sel + l);
+        ticket = 0;
+        if (leader) ticket = lazy_ticket(queue);
     }
     __device__ __forceinline__ void level1(const GridView &g) {
-        eb = g.esup_ptr[p];
-        fb = g.fsup_ptr[p];
+        settle(p, dsc, ticket);
+        eb = lazy_u32(g.esup_ptr + p);
+        fb = lazy_u32(g.fsup_ptr + p);
+        flag = lazy_u8(g.flags + p);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xv[k] = g.coords[3 * (size_t)p + k];
+        for (int k = 0; k < 3; ++k) xv[k] = lazy_f64(g.coords + 3 * (size_t)p + k);
     }
     __device__ __forceinline__ void level2(const GridView &g) {
-        ce = g.esup[eb + (dsc & 7)];
-        co = g.esup[eb + ((dsc >> 3) & 7)];
+        settle(eb, fb, flag, xv[0], xv[1], xv[2]);
+        id[0] = lazy_u32(g.esup + eb + (dsc & 7));
+        id[1] = lazy_u32(g.esup + eb + ((dsc >> 3) & 7));
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const uint32_t w = dsc >> (6 + 8 * i);
-            f[i] = (size_t)g.fsup[fb + (w & 15)];
-            cn[i] = g.esup[eb + ((w >> 4) & 7)];
+            id[2 + i] = lazy_u32(g.esup + eb + ((w >> 4) & 7));
+            id[5 + i] = lazy_u32(g.fsup + fb + (w & 15));
         }
     }
     __device__ __forceinline__ void level3(const GridView &g) {
+        settle(id);
+        const uint32_t ce = id[0], co = id[1];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             cen_e[k] = g.centroids[3 * (size_t)ce + k];
@@ -99,14 +153,15 @@ struct Fetch {
         dme = g.diff_mag[ce];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
+            const uint32_t cn = id[2 + i], f = id[5 + i];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                fcen[i][k] = g.face_center[3 * f[i] + k];
-                fn[i][k] = (double)g.face_normal[3 * f[i] + k];
+                fcen[i][k] = g.face_center[3 * (size_t)f + k];
+                fn[i][k] = (double)g.face_normal[3 * (size_t)f + k];
             }
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Kn[i][k] = g.perm[9 * (size_t)cn[i] + k];
-            dmn[i] = g.diff_mag[cn[i]];
+            for (int k = 0; k < 9; ++k) Kn[i][k] = g.perm[9 * (size_t)cn + k];
+            dmn[i] = g.diff_mag[cn];
         }
     }
 };
@@ -247,29 +302,36 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
         wg_end = n_groups;
         q = queue;
     }
-    auto grab = [&]() -> int32_t {
-        int32_t v = 0;
-        if (lane == 0) v = atomicAdd(q, 1);
-        return wg_lo + __builtin_amdgcn_readfirstlane(v);
-    };
     // lane-role masks (as multipliers): face i of lane l sits on odd slot i (i < 3 - l) or i + 1
     const double mA0 = (l != 3) ? 1.0 : 0.0, mA1 = (l < 2) ? 1.0 : 0.0, mA2 = (l == 0) ? 1.0 : 0.0;
     const double mB1 = (l == 3) ? 1.0 : 0.0, mB2 = (l >= 2) ? 1.0 : 0.0, mB3 = (l != 0) ? 1.0 : 0.0;
 
-    Fetch cur;
-    int32_t wg = grab();
-    while (wg < wg_end) {
-        cur.level0(nodes, desc, wg * NPW + nd, count, l);
-        wg = grab();
+    // The reads of a pass form a dependent chain (work ticket, list entry -> CSR row starts -> ids -> geometry and
+    // permeability): each level of the NEXT pass is issued at a different point of this one and has long landed when
+    // the following level needs it.  The ticket drawn with level 0 of pass n + 1 names the group of pass n + 2.
+    const bool leader = lane == 0;
+    Fetch cur, nx;
+    int32_t wg, wg_next;
+    {
+        uint32_t t0 = 0, t1 = 0, t2 = 0;
+        if (leader) t0 = lazy_ticket(q);
+        settle(t0, t1, t2);
+        wg = wg_lo + (int32_t)__builtin_amdgcn_readfirstlane(t0);
+        cur.level0(nodes, desc, wg * NPW + nd, count, l, q, leader, 0.0);
         cur.level1(g);
+        wg_next = wg_lo + (int32_t)__builtin_amdgcn_readfirstlane(cur.ticket);
         cur.level2(g);
         cur.level3(g);
+    }
+    while (wg < wg_end) {
         const bool valid = cur.valid;
-        const int32_t p = cur.p, eb = cur.eb;
+        const uint32_t p = cur.p, eb = cur.eb;
         const uint32_t dsc = cur.dsc;
+        const bool is_neu = (cur.flag & 2) != 0;
 
         // ---- the front of E_l: rows 0 = cell row, 1 + 3 i + r = row r of face i; own columns in P ------------
-        double P[10][3], de[3], dod[3], nb0[3][3];   // nb0[i] = first row of the neighbour-side block of face i
+        // nb0[i] = first row of the neighbour-side block of face i; its rows 1, 2 are minus the own block's (sav)
+        double P[10][3], de[3], dod[3], nb0[3][3], sav[3][2][3];
         {
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
@@ -296,27 +358,19 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
                     P[1 + 3 * i][t] = sg * (Ke[t * 3 + 0] * N0 + Ke[t * 3 + 1] * N1 + Ke[t * 3 + 2] * N2);
                     nb0[i][t] = -sg * (Kn[t * 3 + 0] * N0 + Kn[t * 3 + 1] * N1 + Kn[t * 3 + 2] * N2);
                 }
-                P[2 + 3 * i][0] = sg * T0; P[2 + 3 * i][1] = sg * T1; P[2 + 3 * i][2] = sg * T2;
-                P[3 + 3 * i][0] = sg * (tj * U0); P[3 + 3 * i][1] = sg * (tj * U1); P[3 + 3 * i][2] = sg * (tj * U2);
+                sav[i][0][0] = sg * T0; sav[i][0][1] = sg * T1; sav[i][0][2] = sg * T2;
+                sav[i][1][0] = sg * (tj * U0); sav[i][1][1] = sg * (tj * U1); sav[i][1][2] = sg * (tj * U2);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { P[2 + 3 * i][t] = sav[i][0][t]; P[3 + 3 * i][t] = sav[i][1][t]; }
             }
         }
-        // ---- the odd-slot blocks of the front, before the panel overwrites the face rows it shares with them -------
-        // slot s takes face s (lanes with s < 3 - l) or face s - 1 (s > 3 - l); rows 1, 2 of a neighbour block are
-        // minus the own block's
+        // next pass: list entry, and the ticket of the pass after it.  Tied to the face rows above: the geometry this
+        // pass has just consumed must have been waited for BEFORE these go out, or that wait covers them too
+        nx.level0(nodes, desc, wg_next * NPW + nd, count, l, q, leader, (P[3][2] + P[6][2]) + P[9][2]);
         double C[NR][NC];
         double u[12], se;
         double g3[3], rinv[3], z[3];
         {
-            double B0[10][3], B1[10][3], B2[10][3], B3[10][3], Bc[10][1];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                B0[1][t] = mA0 * nb0[0][t]; B0[2][t] = -(mA0 * P[2][t]); B0[3][t] = -(mA0 * P[3][t]);
-                B1[1][t] = mB1 * nb0[0][t]; B1[2][t] = -(mB1 * P[2][t]); B1[3][t] = -(mB1 * P[3][t]);
-                B1[4][t] = mA1 * nb0[1][t]; B1[5][t] = -(mA1 * P[5][t]); B1[6][t] = -(mA1 * P[6][t]);
-                B2[4][t] = mB2 * nb0[1][t]; B2[5][t] = -(mB2 * P[5][t]); B2[6][t] = -(mB2 * P[6][t]);
-                B2[7][t] = mA2 * nb0[2][t]; B2[8][t] = -(mA2 * P[8][t]); B2[9][t] = -(mA2 * P[9][t]);
-                B3[7][t] = mB3 * nb0[2][t]; B3[8][t] = -(mB3 * P[8][t]); B3[9][t] = -(mB3 * P[9][t]);
-            }
             // ---- panel: three Householder steps on the own columns; v_k stays in P[k..9][k] ----------------------
             {
                 double ss = 0.0;
@@ -358,33 +412,58 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
             z[0] = de[0] * rinv[0];
             z[1] = fma(-P[0][1], z[0], de[1]) * rinv[1];
             z[2] = fma(-P[1][2], z[1], fma(-P[0][2], z[0], de[2])) * rinv[2];
-            // ---- the reflectors on the odd-slot blocks and on c ---------------------------------------------------
-            apply_panel<3, false, true, false, false>(P, g3, B0);
-            apply_panel<3, false, true, true, false>(P, g3, B1);
-            apply_panel<3, false, false, true, true>(P, g3, B2);
-            apply_panel<3, false, false, false, true>(P, g3, B3);
-            Bc[0][0] = 1.0;                                   // c = e_0 on entry: only the cell row carries a 1
-            apply_panel<1, true, false, false, false>(P, g3, Bc);
-            // rows 0..2 -> u = z^T R_eo and s = z . b_e;  rows 3..9 -> this lane's rows 0..6 of the 32 x 12 problem
+            // ---- the reflectors on the odd-slot blocks and on c, one block at a time.  Slot s takes face s (lanes with
+            //      s < 3 - l) or face s - 1 (s > 3 - l).  Rows 0..2 of a finished block -> u = z^T R_eo (s = z . b_e for
+            //      c), rows 3..9 -> this lane's rows 0..6 of the 32 x 12 problem -----------------------------------------
+#define NIN_FACE_ROWS(B, R0, M, I)                                                                       \
+    _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                      \
+        B[R0][t] = (M) * nb0[I][t]; B[R0 + 1][t] = -((M) * sav[I][0][t]); B[R0 + 2][t] = -((M) * sav[I][1][t]); \
+    }
+#define NIN_TAKE_BLOCK(B, S)                                                                             \
+    _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                      \
+        u[3 * S + t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));                          \
+        _Pragma("unroll") for (int r = 0; r < 7; ++r) C[r][3 * S + t] = B[3 + r][t];                     \
+    }
+            {
+                double Bc[10][1];
+                Bc[0][0] = 1.0;                               // c = e_0 on entry: only the cell row carries a 1
+                apply_panel<1, true, false, false, false>(P, g3, Bc);
+                se = fma(z[2], Bc[2][0], fma(z[1], Bc[1][0], z[0] * Bc[0][0]));
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                u[t] = fma(z[2], B0[2][t], fma(z[1], B0[1][t], z[0] * B0[0][t]));
-                u[3 + t] = fma(z[2], B1[2][t], fma(z[1], B1[1][t], z[0] * B1[0][t]));
-                u[6 + t] = fma(z[2], B2[2][t], fma(z[1], B2[1][t], z[0] * B2[0][t]));
-                u[9 + t] = fma(z[2], B3[2][t], fma(z[1], B3[1][t], z[0] * B3[0][t]));
+                for (int r = 0; r < 7; ++r) C[r][12] = Bc[3 + r][0];
             }
-            se = fma(z[2], Bc[2][0], fma(z[1], Bc[1][0], z[0] * Bc[0][0]));
-#pragma unroll
-            for (int r = 0; r < 7; ++r) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    C[r][t] = B0[3 + r][t];
-                    C[r][3 + t] = B1[3 + r][t];
-                    C[r][6 + t] = B2[3 + r][t];
-                    C[r][9 + t] = B3[3 + r][t];
-                }
-                C[r][12] = Bc[3 + r][0];
+            __builtin_amdgcn_sched_barrier(0);   // one block at a time: hoisted block set-ups cost registers
+            {
+                double B[10][3];
+                NIN_FACE_ROWS(B, 1, mA0, 0)
+                apply_panel<3, false, true, false, false>(P, g3, B);
+                NIN_TAKE_BLOCK(B, 0)
             }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                double B[10][3];
+                NIN_FACE_ROWS(B, 1, mB1, 0)
+                NIN_FACE_ROWS(B, 4, mA1, 1)
+                apply_panel<3, false, true, true, false>(P, g3, B);
+                NIN_TAKE_BLOCK(B, 1)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                double B[10][3];
+                NIN_FACE_ROWS(B, 4, mB2, 1)
+                NIN_FACE_ROWS(B, 7, mA2, 2)
+                apply_panel<3, false, false, true, true>(P, g3, B);
+                NIN_TAKE_BLOCK(B, 2)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                double B[10][3];
+                NIN_FACE_ROWS(B, 7, mB3, 2)
+                apply_panel<3, false, false, false, true>(P, g3, B);
+                NIN_TAKE_BLOCK(B, 3)
+            }
+#undef NIN_FACE_ROWS
+#undef NIN_TAKE_BLOCK
         }
         // row 7: the cell row of O_l, (x_K - x_v) on the columns of odd slot l, c = 1
 #pragma unroll
@@ -396,8 +475,16 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
         C[7][12] = 1.0;
 
         // ---- phase 2: 32 x 12 over the quad ------------------------------------------------------------------
+        nx.level1(g);   // next pass: CSR row starts, node coordinates, flags
         double rinvq[3] = {0.0, 0.0, 0.0};
-        P2Loop<0, 12>::run(C, rinvq, l);
+        P2Loop<0, 6>::run(C, rinvq, l);
+        nx.level2(g);   // next pass: cell and face ids
+        P2Loop<6, 12>::run(C, rinvq, l);
+        // next pass: geometry and permeability.  Issued HERE: the registers phase 2 has just released take them, and
+        // the back-substitution and the weights below (~2.5 k cycles, mostly dependent chains) cover their latency
+        __builtin_amdgcn_sched_barrier(0);
+        nx.level3(g);
+        __builtin_amdgcn_sched_barrier(0);
         double y[12], t3[3] = {C[0][12], C[1][12], C[2][12]};
         BackLoop<11>::run(C, rinvq, t3, y, l);
         double tail = 0.0;
@@ -423,7 +510,6 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
         wbuf[nd * 8 + (dsc & 7)] = we;
         wbuf[nd * 8 + ((dsc >> 3) & 7)] = wo;
         wave_lds_sync();
-        const bool is_neu = (g.flags[p] & 2) != 0;
         // gls.pyx:470-472 (only if an interior node carries the Neumann flag): neumann_ws = the last cell's weight
         const double nwv = is_neu ? wbuf[nd * 8 + 7] : 0.0;
         const double addv = add_neumann ? nwv : 0.0;
@@ -434,6 +520,9 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
             if (l == 0) nws[p] = nwv;
         }
         wave_lds_sync();
+        cur = nx;
+        wg = wg_next;
+        wg_next = wg_lo + (int32_t)__builtin_amdgcn_readfirstlane(nx.ticket);
     }
 }
 

@@ -4,7 +4,7 @@
 # Pass 1: --kernel-trace --stats of the default bench (no CPU-baseline leg).  Passes 2-4: separate --pmc runs
 # (FETCH_SIZE; WRITE_SIZE; SQ counters), never combined with other trace domains.
 set -u
-ROUND=${1:-r01}
+ROUND=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
@@ -20,7 +20,7 @@ python3 - "$OUT" <<'PY'
 import csv, glob, sys, json, collections, os
 out = sys.argv[1]
 def short(k):
-    k = k.replace("void nin::(anonymous namespace)::", "")
+    k = k.replace("void nin::(anonymous namespace)::", "").replace("nin::(anonymous namespace)::", "")
     return k.split("(")[0]
 # kernel stats + head of the trace
 st = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)[0]
@@ -44,7 +44,10 @@ def traffic(prefixes):   # bytes per launch: 2 x FETCH (gfx950 correction, MI355
     for (k, c), v in avg.items():
         if any(k.startswith(p) for p in prefixes): t += v * 1024 * (2 if c == "FETCH_SIZE" else 1 if c == "WRITE_SIZE" else 0)
     return int(t)
-tj = {"note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section: gfx950 tallies 128-B requests at 64 B). pmc_summary.csv of the round holds the raw counters.",
+sys.path.insert(0, os.getcwd())
+import bench
+tj = {"kernel_source_sha16": bench.kernel_source_hash(),
+      "note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section: gfx950 tallies 128-B requests at 64 B). pmc_summary.csv of the round holds the raw counters.",
       "gls_n216_bytes_per_launch": traffic(["nin_gls_"]),
       "idw_n216_bytes_per_launch": traffic(["nin_rows_kernel<0>"]),   # kernels_idw_ls.hip: METHOD 0 = IDW, 1 = LS
       "ls_n216_bytes_per_launch": traffic(["nin_rows_kernel<1>"])}
