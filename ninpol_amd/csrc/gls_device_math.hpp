@@ -38,6 +38,19 @@ __device__ __forceinline__ double fast_rsqrt(double s) {
 struct House {
     double beta, vp, g, rinv;
 };
+// The same without the x = 0 branch.  x = 0, alpha != 0 needs none: beta = -alpha, v = (2 alpha, 0), H flips the sign of
+// the pivot row -- orthogonal all the same.  A column that is zero altogether (S = 0) turns into NaNs here, which the
+// caller's final finiteness test maps to the zero row a rank-deficient system gets anyway.
+__device__ __forceinline__ House house_unguarded(double alpha, double ss) {
+    const double S = fma(alpha, alpha, ss);
+    const double rs = fast_rsqrt(S), sq = S * rs;
+    House h;
+    h.beta = -copysign(sq, alpha);
+    h.vp = alpha - h.beta;
+    h.g = fast_rcp(fma(fabs(alpha), sq, S));
+    h.rinv = -(h.g * h.vp);
+    return h;
+}
 __device__ __forceinline__ House house(double alpha, double ss) {
     const bool live = ss != 0.0;
     const double S = fma(alpha, alpha, ss);

@@ -53,6 +53,10 @@ __device__ __forceinline__ double quad_sum(double v) {
 template <int L>
 __device__ __forceinline__ double quad_bcast(double v) { return dpp_mov<L * 0x55>(v); }   // quad_perm [L,L,L,L]
 
+// Computed HERE: without it the optimiser sinks a value's whole computation down to its first use -- for u, s and z
+// that is the end of the pass, with the rows of R they are made from parked in ~140 AGPRs across phase 2.
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+
 constexpr int NPW = 16;          // nodes per wavefront pass (4 lanes each)
 constexpr int NR = 8, NC = 13;   // phase 2, per lane: 8 rows x (12 odd columns + c)
 
@@ -231,7 +235,7 @@ __device__ __forceinline__ void p2_step(double (&C)[NR][NC], double (&rinvq)[3],
     }
     ss = quad_sum(ss);
     const double alpha = quad_bcast<LAM>(C[Q][K]);
-    const House h = house(alpha, ss);
+    const House h = house_unguarded(alpha, ss);
     rinvq[Q] = is_piv ? h.rinv : rinvq[Q];
     const double vpl = is_piv ? h.vp : 0.0;           // the pivot entry of v, in the pivot lane only
     const double vq = is_piv ? h.vp : xq;             // row Q's entry of v in this lane
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
                 double ss = 0.0;
 #pragma unroll
                 for (int r = 1; r < 10; ++r) ss = fma(P[r][0], P[r][0], ss);
-                const House h = house(P[0][0], ss);
+                const House h = house_unguarded(P[0][0], ss);
                 g3[0] = h.g; rinv[0] = h.rinv;
                 double d1 = h.vp * P[0][1], d2 = h.vp * P[0][2];
 #pragma unroll
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
                 double ss = 0.0;
 #pragma unroll
                 for (int r = 2; r < 10; ++r) ss = fma(P[r][1], P[r][1], ss);
-                const House h = house(P[1][1], ss);
+                const House h = house_unguarded(P[1][1], ss);
                 g3[1] = h.g; rinv[1] = h.rinv;
                 double d2 = h.vp * P[1][2];
 #pragma unroll
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
                 double ss = 0.0;
 #pragma unroll
                 for (int r = 3; r < 10; ++r) ss = fma(P[r][2], P[r][2], ss);
-                const House h = house(P[2][2], ss);
+                const House h = house_unguarded(P[2][2], ss);
                 g3[2] = h.g; rinv[2] = h.rinv;
                 P[2][2] = h.vp;
             }
@@ -412,6 +416,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
             z[0] = de[0] * rinv[0];
             z[1] = fma(-P[0][1], z[0], de[1]) * rinv[1];
             z[2] = fma(-P[1][2], z[1], fma(-P[0][2], z[0], de[2])) * rinv[2];
+            pin(z[0]); pin(z[1]); pin(z[2]);
             // ---- the reflectors on the odd-slot blocks and on c, one block at a time.  Slot s takes face s (lanes with
             //      s < 3 - l) or face s - 1 (s > 3 - l).  Rows 0..2 of a finished block -> u = z^T R_eo (s = z . b_e for
             //      c), rows 3..9 -> this lane's rows 0..6 of the 32 x 12 problem -----------------------------------------
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
 #define NIN_TAKE_BLOCK(B, S)                                                                             \
     _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                      \
         u[3 * S + t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));                          \
+        pin(u[3 * S + t]);                                                                               \
         _Pragma("unroll") for (int r = 0; r < 7; ++r) C[r][3 * S + t] = B[3 + r][t];                     \
     }
             {
@@ -429,6 +435,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
                 Bc[0][0] = 1.0;                               // c = e_0 on entry: only the cell row carries a 1
                 apply_panel<1, true, false, false, false>(P, g3, Bc);
                 se = fma(z[2], Bc[2][0], fma(z[1], Bc[1][0], z[0] * Bc[0][0]));
+                pin(se);
 #pragma unroll
                 for (int r = 0; r < 7; ++r) C[r][12] = Bc[3 + r][0];
             }
@@ -501,10 +508,13 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
         for (int s = 0; s < 4; ++s) dots[s] = fma(dod[2], y[3 * s + 2], fma(dod[1], y[3 * s + 1], dod[0] * y[3 * s]));
         const double dsel = (l == 0) ? dots[0] : (l == 1) ? dots[1] : (l == 2) ? dots[2] : dots[3];
         const double ro = 1.0 - dsel;
-        double we = re / rr, wo = ro / rr;
-        const bool ok = rr > 0.0;                                // rank-deficient system: undefined in the reference, 0 here
-        we = (ok && we - we == 0.0) ? we : 0.0;
-        wo = (ok && wo - wo == 0.0) ? wo : 0.0;
+        const double rri = fast_rcp(rr);
+        double we = re * rri, wo = ro * rri;
+        // rank-deficient system (or NaN from a zero column): undefined in the reference, the zero row here.
+        // (isfinite, not w - w == 0: with the product above, contraction turns that into fma(re, rri, -w) != 0)
+        const bool ok = rr > 0.0;
+        we = (ok && __builtin_isfinite(we)) ? we : 0.0;
+        wo = (ok && __builtin_isfinite(wo)) ? wo : 0.0;
 
         // ---- out: the node's 8 weights in esup order, written as 16-byte pieces ---------------------------------
         wbuf[nd * 8 + (dsc & 7)] = we;
