@@ -7,7 +7,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libninpol_amd.so")
+# NINPOL_AMD_LIB: another build of the same library (A/B timing of kernel variants in one GPU session)
+LIB_PATH = os.environ.get("NINPOL_AMD_LIB") or os.path.join(HERE, "libninpol_amd.so")
 
 NIN_OK = 0
 NIN_EINVAL, NIN_ENOMEM, NIN_EHIP, NIN_ENODEVICE, NIN_ERANGE, NIN_ESTATE = -1, -2, -3, -4, -5, -6
