@@ -40,9 +40,10 @@ constexpr int kGlsClasses = 5;  // four LDS budget classes (1 / 2 / 4 / 8 waves 
 NIN_HD inline int32_t gls_class_budget(int c) { return c == 0 ? 10240 : c == 1 ? 32768 : c == 2 ? 81920 : c == 3 ? 159744 : 0; }
 NIN_HD inline int32_t gls_class_waves(int c) { return c == 0 ? 1 : c == 1 ? 2 : c == 2 ? 4 : c == 3 ? 8 : 1; }
 // LDS bytes of one node's system in the block kernel (kernels_gls_block.hip): the work-queue word, (n + 1) columns of odd pitch m | 1,
-// the partial-dot buffers (later y and the weight row) and the staged cell ids
+// the partial-dot buffers (later y and the weight row), the staged cell ids and their column blocks
 NIN_HD inline int64_t gls_block_lds_bytes(int64_t ne, int64_t m, int64_t n, int waves) {
-    const int64_t doubles = 2 + (n + 1) * (m | 1) + (waves == 1 ? 2 : (waves != 4 ? 2 : 1) * waves) * n + ((ne + 1) >> 1);
+    const int64_t doubles = 2 + (n + 1) * (m | 1) + (waves == 1 ? 2 : (waves != 4 ? 2 : 1) * waves) * n + ((ne + 1) >> 1) +
+                            ((ne + 7) >> 3);   // + the cells' column blocks (uint8)
     return ((doubles * 8 + 15) / 16) * 16;
 }
 // Size class of a node with ne cells, nf faces of which nbf on the boundary; *bytes = what it needs there.

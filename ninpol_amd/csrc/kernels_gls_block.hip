@@ -109,14 +109,14 @@ __device__ __forceinline__ double *lane_column(const Sys &s, int q, bool has) {
     return s.A + (has ? (s.n - 1 - (s.lane + 64 * q)) : s.n) * s.ld;
 }
 
-// Dots of column 0 with every column, over this wave's rows: what step 0 starts from.
+// Dots of column k0 with every column, over this wave's rows from k0 on: what step k0 (the first dense step) starts from.
 template <int NW, int CS, int TOP>
-__device__ __forceinline__ void first_dots(const Sys &s, double (&dn)[CS]) {
-    const int l0 = (s.n - 1) & 63;
+__device__ __forceinline__ void first_dots(const Sys &s, int k0, double (&dn)[CS]) {
+    const int l0 = (s.n - 1 - k0) & 63;
     const double *col[TOP + 1];
 #pragma unroll
     for (int q = 0; q <= TOP; ++q) col[q] = lane_column(s, q, s.lane + 64 * q < s.n);
-    for (int i = s.wave; i < s.m; i += NW) {
+    for (int i = k0 + ((s.wave - k0) % NW + NW) % NW; i < s.m; i += NW) {
         double own[TOP + 1];
 #pragma unroll
         for (int q = 0; q <= TOP; ++q) own[q] = col[q][i];
@@ -256,6 +256,82 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
     }
 }
 
+// ---- sparse first phase (NW > 1) ---------------------------------------------------------------------------------
+// The cells around the node are the vertices and its internal faces the edges of a graph (a face row couples exactly
+// its two cells).  Cells that share no face are INDEPENDENT: the column of one has no non-zero in the rows of another,
+// so the Householder steps on their columns are independent too, each confined to its "front" -- the cell's own row
+// and the rows of its faces, 10 rows for a cell with 3 faces at the node -- instead of sweeping all m rows.  The
+// kernel picks a maximal independent set C (greedy in esup order; the cube graph of a hexahedron node and the
+// truncated octahedron of a Kuhn-tetrahedra node are bipartite: half the cells), numbers C's columns first and lays
+// the rows out so that the dense convention "step k pivots on row k" still holds:
+//     rows 3 r .. 3 r + 2       the three pivot rows of front r (cell row, first two rows of its first face)
+//     rows L0_r .. L0_r + nL_r  the rest of front r (3 nfi - 2 rows), all L blocks behind the pivot rows
+//     then the rows of the other cells, of the faces between two of them, and the Neumann rows.
+// Phase 1: wave w factors the fronts r = w (mod NW) on its own -- different fronts touch different rows, so there is
+// not one workgroup barrier in it.  What is left is the dense problem on the columns >= 3 |C| and the rows >= 3 |C|,
+// which the sweep of qr_step takes from k = 3 |C| on.  Kuhn tetrahedra: 36 steps of ~10 rows + 36 dense steps on <= 96
+// rows instead of 72 steps on <= 132.  Same mathematics as before (a Householder QR with a column / row permutation).
+struct Plan {               // per node, in the (not yet used) partial-dot buffers
+    unsigned long long *adj;   // [ne] neighbour masks
+    unsigned long long *blocked;   // cells that own a Neumann row (a non-zero of their columns outside their front)
+    int32_t *nfi;              // [ne] internal faces per cell; later the per-cell face counter
+    int16_t *crow;             // [ne] row of the cell row
+    int16_t *lst;              // [ne] per front rank: first row of its L block
+    int16_t *nl;               // [ne] per front rank: rows in its L block
+    int16_t *frow;             // [nf][3] rows of a face (a Neumann face: [0] only)
+    uint8_t *fi;               // [nf][2] positions of the face's cells in the esup row (0xFF: none)
+};
+
+template <int CS>
+__device__ __forceinline__ void front_qr(const Sys &s, int rk, int L0, int nL, volatile int32_t *sing) {
+    const int n = s.n, ld = s.ld, lane = s.lane;
+    double *col[CS];
+    int cidx[CS];
+#pragma unroll
+    for (int q = 0; q < CS; ++q) {
+        const int jj = lane + 64 * q;
+        cidx[q] = jj < n ? n - 1 - jj : -1;              // this lane's column in slot q
+        col[q] = lane_column(s, q, jj < n);
+    }
+    for (int t = 0; t < 3; ++t) {
+        const int k = 3 * rk + t, pend = 3 * rk + 3;       // pivot row k, further pivot rows up to pend, then the L block
+        const double *xc = s.A + (size_t)k * ld;           // the pivot column, read by every lane (LDS broadcast)
+        double d[CS], rowk[CS], w[CS];
+#pragma unroll
+        for (int q = 0; q < CS; ++q) { d[q] = 0.0; rowk[q] = col[q][k]; }
+        double dk = 0.0;
+        for (int r = k; r < pend + nL; ++r) {
+            const int i = r < pend ? r : L0 + (r - pend);
+            const double x = xc[i];
+            dk = fma(x, x, dk);
+#pragma unroll
+            for (int q = 0; q < CS; ++q) d[q] = fma(x, col[q][i], d[q]);
+        }
+        const double alpha = xc[k];
+        if (!(dk != 0.0)) *sing = 1;                        // an all-zero pivot column (or NaN): no solution row
+        const double sq = dk * fast_rsqrt(dk);
+        const double beta = -copysign(sq, alpha);
+        const double inv = fast_rcp(fma(fabs(alpha), sq, dk));
+        const double vk = alpha - beta;
+#pragma unroll
+        for (int q = 0; q < CS; ++q) w[q] = cidx[q] > k ? (d[q] - beta * rowk[q]) * inv : 0.0;
+        group_sync<1>();                                    // every lane has read the pivot column
+        for (int r = k + 1; r < pend + nL; ++r) {
+            const int i = r < pend ? r : L0 + (r - pend);
+            const double x = xc[i];
+#pragma unroll
+            for (int q = 0; q < CS; ++q)
+                if (cidx[q] > k) col[q][i] = fma(-x, w[q], col[q][i]);
+        }
+#pragma unroll
+        for (int q = 0; q < CS; ++q) {
+            if (cidx[q] > k) col[q][k] = fma(-vk, w[q], rowk[q]);   // row k of R
+            if (cidx[q] == k) col[q][k] = beta;
+        }
+        group_sync<1>();
+    }
+}
+
 template <int NW, int CS>
 __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                                  int32_t count, int add_neumann,
@@ -329,14 +405,169 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
 #else
         s.stamps = nullptr;
 #endif
-        int32_t *cells = reinterpret_cast<int32_t *>(s.aux + (NW == 1 ? 2 : (DB ? 2 : 1) * NW) * n);
+        constexpr int AUXW = NW == 1 ? 2 : (DB ? 2 : 1) * NW;   // the partial-dot buffers: AUXW * n doubles
+        int32_t *cells = reinterpret_cast<int32_t *>(s.aux + AUXW * n);
+        uint8_t *cpos = reinterpret_cast<uint8_t *>(cells + 2 * ((ne + 1) >> 1));   // [ne] column block of a cell (SPARSE)
+        constexpr bool SPARSE = NW > 1;
+        volatile int32_t *sing = slot + 2, *n1_word = slot + 3;
+
+        // the plan lives in the partial-dot buffers, which nothing uses before the first dense step
+        Plan pl;
+        bool plan_fits = false;
+        if (SPARSE) {
+            char *pa = reinterpret_cast<char *>(s.aux);
+            pl.adj = reinterpret_cast<unsigned long long *>(pa); pa += 8 * (size_t)ne;
+            pl.blocked = reinterpret_cast<unsigned long long *>(pa); pa += 8;
+            pl.nfi = reinterpret_cast<int32_t *>(pa); pa += 4 * (size_t)((ne + 1) & ~1);
+            pl.crow = reinterpret_cast<int16_t *>(pa); pa += 2 * (size_t)((ne + 3) & ~3);
+            pl.lst = reinterpret_cast<int16_t *>(pa); pa += 2 * (size_t)((ne + 3) & ~3);
+            pl.nl = reinterpret_cast<int16_t *>(pa); pa += 2 * (size_t)((ne + 3) & ~3);
+            pl.frow = reinterpret_cast<int16_t *>(pa); pa += 6 * (size_t)((nf + 3) & ~3);
+            pl.fi = reinterpret_cast<uint8_t *>(pa); pa += 2 * (size_t)nf;
+            plan_fits = ne <= 64 && (size_t)(pa - reinterpret_cast<char *>(s.aux)) <= (size_t)AUXW * n * 8;
+        }
 
         for (int i = tid; i < (n + 1) * ld; i += nthr) s.A[i] = 0.0;
         for (int i = tid; i < ne; i += nthr) cells[i] = g.esup[eb + i];
+        if (SPARSE) {
+            if (plan_fits)
+                for (int i = tid; i < ne; i += nthr) { pl.adj[i] = 0ull; pl.nfi[i] = 0; }
+            if (tid == 0) { *sing = 0; *n1_word = 0; if (plan_fits) *pl.blocked = 0ull; }
+        }
         group_sync<NW>();
 
         const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1],
                      xv2 = g.coords[3 * (size_t)p + 2];
+        if (SPARSE && plan_fits) {
+            // ---- the plan: cell graph (wave 0, a lane per face), then rows and columns (one lane, serial: ~ne + nf steps) --
+            if (wave == 0) {
+                for (int f0 = 0; f0 < nf; f0 += 64) {
+                    const int fi = f0 + lane;
+                    if (fi < nf) {
+                        const size_t f = (size_t)g.fsup[fb + fi];
+                        const int ca = g.face_cells[2 * f], cb = g.face_cells[2 * f + 1];
+                        int Ia = 0, Ib = 0;
+                        for (int q = 0; q < ne; ++q) {
+                            const int cq = cells[q];
+                            Ia = cq == ca ? q : Ia;
+                            Ib = cq == cb ? q : Ib;
+                        }
+                        pl.fi[2 * fi] = (uint8_t)Ia;
+                        pl.fi[2 * fi + 1] = cb >= 0 ? (uint8_t)Ib : (uint8_t)0xFF;
+                        if (cb < 0 && is_neu) atomicOr(pl.blocked, 1ull << Ia);
+                        if (cb >= 0) {
+                            atomicOr(&pl.adj[Ia], 1ull << Ib);
+                            atomicOr(&pl.adj[Ib], 1ull << Ia);
+                            atomicAdd(&pl.nfi[Ia], 1);
+                            atomicAdd(&pl.nfi[Ib], 1);
+                        }
+                    }
+                }
+                group_sync<1>();
+                if (lane == 0) {
+                    unsigned long long chosen = 0ull;
+                    const unsigned long long blocked = *pl.blocked;
+                    for (int c = 0; c < ne; ++c)          // greedy maximal independent set, esup order
+                        if (pl.nfi[c] >= 1 && !(pl.adj[c] & chosen) && !((blocked >> c) & 1ull)) chosen |= 1ull << c;
+                    const int n1 = __popcll(chosen);
+                    int run = 3 * n1, rank = 0, others = 0;
+                    for (int c = 0; c < ne; ++c)
+                        if ((chosen >> c) & 1ull) {
+                            const int rest = 3 * pl.nfi[c] - 2;
+                            pl.crow[c] = (int16_t)(3 * rank);
+                            cpos[c] = (uint8_t)rank;
+                            pl.lst[rank] = (int16_t)run;
+                            pl.nl[rank] = (int16_t)rest;
+                            run += rest;
+                            pl.nfi[c] = 0;                 // from here on: faces of the front placed so far
+                            ++rank;
+                        }
+                    for (int c = 0; c < ne; ++c)
+                        if (!((chosen >> c) & 1ull)) {
+                            pl.crow[c] = (int16_t)run++;
+                            cpos[c] = (uint8_t)(n1 + others++);
+                        }
+                    for (int fi = 0; fi < nf; ++fi) {
+                        const int a = pl.fi[2 * fi], b = pl.fi[2 * fi + 1];
+                        int16_t *fr = pl.frow + 3 * fi;
+                        if (b != 0xFF) {
+                            const int c = ((chosen >> a) & 1ull) ? a : (((chosen >> b) & 1ull) ? b : -1);
+                            if (c >= 0) {
+                                const int sl = pl.nfi[c]++, rk = cpos[c];
+                                if (sl == 0) {
+                                    fr[0] = (int16_t)(3 * rk + 1); fr[1] = (int16_t)(3 * rk + 2); fr[2] = pl.lst[rk];
+                                } else {
+                                    const int base = pl.lst[rk] + 1 + 3 * (sl - 1);
+                                    fr[0] = (int16_t)base; fr[1] = (int16_t)(base + 1); fr[2] = (int16_t)(base + 2);
+                                }
+                            } else {
+                                fr[0] = (int16_t)run; fr[1] = (int16_t)(run + 1); fr[2] = (int16_t)(run + 2);
+                                run += 3;
+                            }
+                        } else if (is_neu) {
+                            fr[0] = (int16_t)run++;
+                        }
+                    }
+                    *n1_word = n1;
+                }
+            }
+            group_sync<NW>();
+            // ---- assembly through the plan's row / column maps ----------------------------------------------------------
+            if (wave == 1) {
+                // cell rows: [x_K - x_v] on the cell's own block, 1 in the last column (gls.pyx:269-281)
+                for (int i = lane; i < ne; i += 64) {
+                    const size_t c = (size_t)cells[i];
+                    double *row = s.A + pl.crow[i];
+                    const int cb3 = 3 * cpos[i];
+                    row[(cb3 + 0) * ld] = g.centroids[3 * c + 0] - xv0;
+                    row[(cb3 + 1) * ld] = g.centroids[3 * c + 1] - xv1;
+                    row[(cb3 + 2) * ld] = g.centroids[3 * c + 2] - xv2;
+                    row[(n - 1) * ld] = 1.0;
+                }
+            }
+            if (wave == 0) {
+                for (int f0 = 0; f0 < nf; f0 += 64) {
+                    const int fi = f0 + lane;
+                    if (fi >= nf) continue;
+                    const size_t f = (size_t)g.fsup[fb + fi];
+                    const int Ia = pl.fi[2 * fi], Ib = pl.fi[2 * fi + 1];
+                    const int16_t *fr = pl.frow + 3 * fi;
+                    const double N0 = g.face_normal[3 * f + 0], N1 = g.face_normal[3 * f + 1], N2 = g.face_normal[3 * f + 2];
+                    if (Ib != 0xFF) {
+                        const int ca = cells[Ia], cb = cells[Ib];
+                        const double T0 = xv0 - g.face_center[3 * f + 0], T1 = xv1 - g.face_center[3 * f + 1],
+                                     T2 = xv2 - g.face_center[3 * f + 2];
+                        // T_sj2 = N x T_sj1, tau = |T_sj2|^(-eta), eta = max diff_mag of the two cells (gls.pyx:304-318)
+                        const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+                        const double da = g.diff_mag[ca], db = g.diff_mag[cb];
+                        double eta = 0.0;
+                        eta = da > eta ? da : eta;
+                        eta = db > eta ? db : eta;
+                        const double tj = pow(sqrt(U0 * U0 + U1 * U1 + U2 * U2), -eta);
+                        const double *Ka = g.perm + 9 * (size_t)ca, *Kb = g.perm + 9 * (size_t)cb;
+                        double *ra = s.A + (size_t)(3 * cpos[Ia]) * ld, *rb = s.A + (size_t)(3 * cpos[Ib]) * ld;
+                        const int r0 = fr[0], r1 = fr[1], r2 = fr[2];   // rows: K N, T1, tau T2
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const double nLa = Ka[c * 3 + 0] * N0 + Ka[c * 3 + 1] * N1 + Ka[c * 3 + 2] * N2;  // row c of K . N
+                            const double nLb = Kb[c * 3 + 0] * N0 + Kb[c * 3 + 1] * N1 + Kb[c * 3 + 2] * N2;
+                            const double t1 = c == 0 ? T0 : (c == 1 ? T1 : T2);
+                            const double u = tj * (c == 0 ? U0 : (c == 1 ? U1 : U2));
+                            ra[c * ld + r0] = -nLa; rb[c * ld + r0] = nLb;
+                            ra[c * ld + r1] = -t1;  rb[c * ld + r1] = t1;
+                            ra[c * ld + r2] = -u;   rb[c * ld + r2] = u;
+                        }
+                    } else if (is_neu) {  // set_neumann_rows, gls.pyx:394-416 (its RHS column is never read back)
+                        const double *Ka = g.perm + 9 * (size_t)cells[Ia];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            s.A[(size_t)(3 * cpos[Ia] + c) * ld + fr[0]] = -(Ka[c * 3 + 0] * N0 + Ka[c * 3 + 1] * N1 + Ka[c * 3 + 2] * N2);
+                    }
+                }
+            }
+        } else {
+        if (SPARSE)
+            for (int i = tid; i < ne; i += nthr) cpos[i] = (uint8_t)i;
         if (wave == (NW > 1 ? 1 : 0)) {
             // cell rows: [x_K - x_v] on the cell's own block, 1 in the last column (gls.pyx:269-281)
             for (int i = lane; i < ne; i += 64) {
@@ -404,16 +635,26 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                 bf_base += __popcll(mb);
             }
         }
+        }
         group_sync<NW>();
 
-        // ---- Householder QR of the first n-1 columns, the last one carried along -----------------------------
+        // ---- phase 1 (SPARSE): the fronts of the independent cells, a wave each, no barrier between them -------------
+        int R0 = 0;
+        if (SPARSE) {
+            const int n1 = ufirst(*n1_word);
+            R0 = 3 * n1;
+            for (int rk = wave; rk < n1; rk += NW) front_qr<CS>(s, rk, pl.lst[rk], pl.nl[rk], sing);
+            group_sync<NW>();
+        }
+
+        // ---- Householder QR of the remaining columns R0 .. n-2, the last one carried along ---------------------------
         bool singular = false;
         double dn[CS], rkeep[CS];
 #pragma unroll
         for (int q = 0; q < CS; ++q) { dn[q] = 0.0; rkeep[q] = 0.0; }
         {
-            const int top0 = (n - 1) >> 6;
-#define NIN_TOP(T) if (CS > T && top0 == T) first_dots<NW, CS, T>(s, dn)
+            const int top0 = (n - 1 - R0) >> 6;
+#define NIN_TOP(T) if (CS > T && top0 == T) first_dots<NW, CS, T>(s, R0, dn)
             NIN_TOP(0); NIN_TOP(1); NIN_TOP(2); NIN_TOP(3);
 #undef NIN_TOP
         }
@@ -425,8 +666,8 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                 if (lane + 64 * q < n) P[lane + 64 * q] = dn[q];
             group_sync<NW>();
         }
-        for (int k = 0; k < n - 1; ++k) {
-            if (k > 0 && wave == (k - 1) % NW) {   // row k-1 of R: every wave has finished reading it as a pivot row
+        for (int k = R0; k < n - 1; ++k) {
+            if (k > R0 && wave == (k - 1) % NW) {   // row k-1 of R: every wave has finished reading it as a pivot row
 #pragma unroll
                 for (int q = 0; q < CS; ++q) {
                     const int jj = lane + 64 * q;
@@ -482,7 +723,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             }
             rr = wave_sum(rr);
             group_sync<1>();
-            singular = singular || !(rr > 0.0);
+            singular = singular || !(rr > 0.0) || (SPARSE && *sing != 0);
             const double irr = 1.0 / rr;
             for (int i = lane; i < ne; i += 64) {
                 const double *row = s.A;   // the cell rows were consumed by the QR: rebuild x_K - x_v as assembled
@@ -490,7 +731,8 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                 const size_t c = (size_t)cells[i];
                 const double d0 = g.centroids[3 * c + 0] - xv0, d1 = g.centroids[3 * c + 1] - xv1,
                              d2 = g.centroids[3 * c + 2] - xv2;
-                const double r = 1.0 - (d0 * y[3 * i + 0] + d1 * y[3 * i + 1] + d2 * y[3 * i + 2]);
+                const int ci = SPARSE ? 3 * (int)cpos[i] : 3 * i;   // the cell's column block
+                const double r = 1.0 - (d0 * y[ci + 0] + d1 * y[ci + 1] + d2 * y[ci + 2]);
                 wrow[i] = singular ? 0.0 : r * irr;
             }
             group_sync<1>();
