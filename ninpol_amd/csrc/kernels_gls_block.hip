@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "device_grid.hpp"
+#include "gls_device_math.hpp"
 #include "launch.hpp"
 
 namespace nin {
@@ -282,9 +283,14 @@ struct Plan {               // per node, in the (not yet used) partial-dot buffe
     uint8_t *fi;               // [nf][2] positions of the face's cells in the esup row (0xFF: none)
 };
 
+// One front, one wave: its rows (3 pivot rows + the L block, at most 13 for a cell with 4 faces at the node) are
+// taken into registers -- lane = column, as everywhere in this file -- factored there with the pivot column's entries
+// broadcast by v_readlane, and written back once.
 template <int CS>
-__device__ __forceinline__ void front_qr(const Sys &s, int rk, int L0, int nL, volatile int32_t *sing) {
-    const int n = s.n, ld = s.ld, lane = s.lane;
+__device__ __forceinline__ bool front_qr(const Sys &s, int rk, int L0, int nL) {
+    constexpr int MAXR = 13;
+    const int n = s.n, lane = s.lane, nr = 3 + nL;
+    bool bad = false;
     double *col[CS];
     int cidx[CS];
 #pragma unroll
@@ -293,43 +299,60 @@ __device__ __forceinline__ void front_qr(const Sys &s, int rk, int L0, int nL, v
         cidx[q] = jj < n ? n - 1 - jj : -1;              // this lane's column in slot q
         col[q] = lane_column(s, q, jj < n);
     }
-    for (int t = 0; t < 3; ++t) {
-        const int k = 3 * rk + t, pend = 3 * rk + 3;       // pivot row k, further pivot rows up to pend, then the L block
-        const double *xc = s.A + (size_t)k * ld;           // the pivot column, read by every lane (LDS broadcast)
-        double d[CS], rowk[CS], w[CS];
+    double a[MAXR][CS];
 #pragma unroll
-        for (int q = 0; q < CS; ++q) { d[q] = 0.0; rowk[q] = col[q][k]; }
-        double dk = 0.0;
-        for (int r = k; r < pend + nL; ++r) {
-            const int i = r < pend ? r : L0 + (r - pend);
-            const double x = xc[i];
-            dk = fma(x, x, dk);
+    for (int r = 0; r < MAXR; ++r) {
+        const int i = r < 3 ? 3 * rk + r : L0 + (r - 3);
 #pragma unroll
-            for (int q = 0; q < CS; ++q) d[q] = fma(x, col[q][i], d[q]);
+        for (int q = 0; q < CS; ++q) a[r][q] = 0.0;
+        if (r < nr) {
+#pragma unroll
+            for (int q = 0; q < CS; ++q) a[r][q] = col[q][i];
         }
-        const double alpha = xc[k];
-        if (!(dk != 0.0)) *sing = 1;                        // an all-zero pivot column (or NaN): no solution row
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int k = 3 * rk + t, jjk = n - 1 - k, lk = jjk & 63, qk = jjk >> 6;   // pivot column: lane lk of slot qk
+        double x[MAXR], d[CS], w[CS];
+        double dk = 0.0;
+#pragma unroll
+        for (int q = 0; q < CS; ++q) d[q] = 0.0;
+#pragma unroll
+        for (int r = t; r < MAXR; ++r) {
+            double v = a[r][0];
+#pragma unroll
+            for (int q = 1; q < CS; ++q) v = qk == q ? a[r][q] : v;
+            x[r] = readlane_f64(v, lk);
+            dk = fma(x[r], x[r], dk);
+#pragma unroll
+            for (int q = 0; q < CS; ++q) d[q] = fma(x[r], a[r][q], d[q]);
+        }
+        const double alpha = x[t];
+        bad = bad || !(dk != 0.0);                          // an all-zero pivot column (or NaN): no solution row
         const double sq = dk * fast_rsqrt(dk);
         const double beta = -copysign(sq, alpha);
         const double inv = fast_rcp(fma(fabs(alpha), sq, dk));
         const double vk = alpha - beta;
 #pragma unroll
-        for (int q = 0; q < CS; ++q) w[q] = cidx[q] > k ? (d[q] - beta * rowk[q]) * inv : 0.0;
-        group_sync<1>();                                    // every lane has read the pivot column
-        for (int r = k + 1; r < pend + nL; ++r) {
-            const int i = r < pend ? r : L0 + (r - pend);
-            const double x = xc[i];
+        for (int q = 0; q < CS; ++q) w[q] = cidx[q] > k ? (d[q] - beta * a[t][q]) * inv : 0.0;
+#pragma unroll
+        for (int r = t + 1; r < MAXR; ++r) {
+#pragma unroll
+            for (int q = 0; q < CS; ++q) a[r][q] = fma(-x[r], w[q], a[r][q]);
+        }
+#pragma unroll
+        for (int q = 0; q < CS; ++q) a[t][q] = cidx[q] == k ? beta : fma(-vk, w[q], a[t][q]);   // row k of R
+    }
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int i = r < 3 ? 3 * rk + r : L0 + (r - 3);
+        if (r < nr) {
 #pragma unroll
             for (int q = 0; q < CS; ++q)
-                if (cidx[q] > k) col[q][i] = fma(-x, w[q], col[q][i]);
+                if (cidx[q] >= 3 * rk) col[q][i] = a[r][q];
         }
-#pragma unroll
-        for (int q = 0; q < CS; ++q) {
-            if (cidx[q] > k) col[q][k] = fma(-vk, w[q], rowk[q]);   // row k of R
-            if (cidx[q] == k) col[q][k] = beta;
-        }
-        group_sync<1>();
     }
+    return bad;
 }
 
 template <int NW, int CS>
@@ -424,7 +447,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             pl.nl = reinterpret_cast<int16_t *>(pa); pa += 2 * (size_t)((ne + 3) & ~3);
             pl.frow = reinterpret_cast<int16_t *>(pa); pa += 6 * (size_t)((nf + 3) & ~3);
             pl.fi = reinterpret_cast<uint8_t *>(pa); pa += 2 * (size_t)nf;
-            plan_fits = ne <= 64 && (size_t)(pa - reinterpret_cast<char *>(s.aux)) <= (size_t)AUXW * n * 8;
+            plan_fits = ne <= 64 && nf <= 64 && (size_t)(pa - reinterpret_cast<char *>(s.aux)) <= (size_t)AUXW * n * 8;
         }
 
         for (int i = tid; i < (n + 1) * ld; i += nthr) s.A[i] = 0.0;
@@ -439,77 +462,93 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
         const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1],
                      xv2 = g.coords[3 * (size_t)p + 2];
         if (SPARSE && plan_fits) {
-            // ---- the plan: cell graph (wave 0, a lane per face), then rows and columns (one lane, serial: ~ne + nf steps) --
+            // ---- the plan, wave 0: a lane per face builds the cell graph, then a lane per cell and a lane per face place
+            //      columns and rows (ballots, one scan, shuffles: no serial pass over LDS) -----------------------------------
             if (wave == 0) {
-                for (int f0 = 0; f0 < nf; f0 += 64) {
-                    const int fi = f0 + lane;
-                    if (fi < nf) {
-                        const size_t f = (size_t)g.fsup[fb + fi];
-                        const int ca = g.face_cells[2 * f], cb = g.face_cells[2 * f + 1];
-                        int Ia = 0, Ib = 0;
-                        for (int q = 0; q < ne; ++q) {
-                            const int cq = cells[q];
-                            Ia = cq == ca ? q : Ia;
-                            Ib = cq == cb ? q : Ib;
-                        }
-                        pl.fi[2 * fi] = (uint8_t)Ia;
-                        pl.fi[2 * fi + 1] = cb >= 0 ? (uint8_t)Ib : (uint8_t)0xFF;
-                        if (cb < 0 && is_neu) atomicOr(pl.blocked, 1ull << Ia);
-                        if (cb >= 0) {
-                            atomicOr(&pl.adj[Ia], 1ull << Ib);
-                            atomicOr(&pl.adj[Ib], 1ull << Ia);
-                            atomicAdd(&pl.nfi[Ia], 1);
-                            atomicAdd(&pl.nfi[Ib], 1);
-                        }
+                const bool face_lane = lane < nf;
+                int Ia = 0, Ib = 0xFF;
+                if (face_lane) {
+                    const size_t f = (size_t)g.fsup[fb + lane];
+                    const int ca = g.face_cells[2 * f], cb = g.face_cells[2 * f + 1];
+                    int ib = 0;
+                    for (int q = 0; q < ne; ++q) {
+                        const int cq = cells[q];
+                        Ia = cq == ca ? q : Ia;
+                        ib = cq == cb ? q : ib;
+                    }
+                    Ib = cb >= 0 ? ib : 0xFF;
+                    pl.fi[2 * lane] = (uint8_t)Ia;
+                    pl.fi[2 * lane + 1] = (uint8_t)Ib;
+                    if (cb < 0 && is_neu) atomicOr(pl.blocked, 1ull << Ia);
+                    if (cb >= 0) {
+                        atomicOr(&pl.adj[Ia], 1ull << Ib);
+                        atomicOr(&pl.adj[Ib], 1ull << Ia);
+                        atomicAdd(&pl.nfi[Ia], 1);
+                        atomicAdd(&pl.nfi[Ib], 1);
                     }
                 }
                 group_sync<1>();
-                if (lane == 0) {
-                    unsigned long long chosen = 0ull;
-                    const unsigned long long blocked = *pl.blocked;
-                    for (int c = 0; c < ne; ++c)          // greedy maximal independent set, esup order
-                        if (pl.nfi[c] >= 1 && !(pl.adj[c] & chosen) && !((blocked >> c) & 1ull)) chosen |= 1ull << c;
-                    const int n1 = __popcll(chosen);
-                    int run = 3 * n1, rank = 0, others = 0;
-                    for (int c = 0; c < ne; ++c)
-                        if ((chosen >> c) & 1ull) {
-                            const int rest = 3 * pl.nfi[c] - 2;
-                            pl.crow[c] = (int16_t)(3 * rank);
-                            cpos[c] = (uint8_t)rank;
-                            pl.lst[rank] = (int16_t)run;
-                            pl.nl[rank] = (int16_t)rest;
-                            run += rest;
-                            pl.nfi[c] = 0;                 // from here on: faces of the front placed so far
-                            ++rank;
-                        }
-                    for (int c = 0; c < ne; ++c)
-                        if (!((chosen >> c) & 1ull)) {
-                            pl.crow[c] = (int16_t)run++;
-                            cpos[c] = (uint8_t)(n1 + others++);
-                        }
-                    for (int fi = 0; fi < nf; ++fi) {
-                        const int a = pl.fi[2 * fi], b = pl.fi[2 * fi + 1];
-                        int16_t *fr = pl.frow + 3 * fi;
-                        if (b != 0xFF) {
-                            const int c = ((chosen >> a) & 1ull) ? a : (((chosen >> b) & 1ull) ? b : -1);
-                            if (c >= 0) {
-                                const int sl = pl.nfi[c]++, rk = cpos[c];
-                                if (sl == 0) {
-                                    fr[0] = (int16_t)(3 * rk + 1); fr[1] = (int16_t)(3 * rk + 2); fr[2] = pl.lst[rk];
-                                } else {
-                                    const int base = pl.lst[rk] + 1 + 3 * (sl - 1);
-                                    fr[0] = (int16_t)base; fr[1] = (int16_t)(base + 1); fr[2] = (int16_t)(base + 2);
-                                }
-                            } else {
-                                fr[0] = (int16_t)run; fr[1] = (int16_t)(run + 1); fr[2] = (int16_t)(run + 2);
-                                run += 3;
-                            }
-                        } else if (is_neu) {
-                            fr[0] = (int16_t)run++;
-                        }
-                    }
-                    *n1_word = n1;
+                // lane c = cell c
+                const bool cell_lane = lane < ne;
+                const unsigned long long my_adj = cell_lane ? pl.adj[lane] : 0ull;
+                const int my_nfi = cell_lane ? pl.nfi[lane] : 0;
+                const unsigned long long blocked = *pl.blocked;
+                const unsigned long long elig = __ballot(cell_lane && my_nfi >= 1 && my_nfi <= 4 && !((blocked >> lane) & 1ull));
+                unsigned long long chosen = 0ull;
+                for (int c = 0; c < ne; ++c) {            // greedy maximal independent set, esup order (scalar work)
+                    const unsigned long long ac = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(my_adj >> 32), c) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readlane((int)my_adj, c);
+                    if (((elig >> c) & 1ull) && !(ac & chosen)) chosen |= 1ull << c;
                 }
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const unsigned long long cellmask = ne >= 64 ? ~0ull : ((1ull << ne) - 1ull);
+                const int n1 = __popcll(chosen), R0p = 3 * n1;
+                const bool is_ch = ((chosen >> lane) & 1ull) != 0;
+                const int rank = __popcll(chosen & below), other = __popcll(~chosen & cellmask & below);
+                const int rest = is_ch ? 3 * my_nfi - 2 : 0;
+                int scan = rest;                           // inclusive scan of the L-block lengths over the cell lanes
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) {
+                    const int up = __shfl_up(scan, sh);
+                    if (lane >= sh) scan += up;
+                }
+                const int total_rest = __builtin_amdgcn_readlane(scan, 63);
+                const int my_lst = R0p + scan - rest;       // first row of this cell's L block (chosen lanes)
+                const int n_other = ne - n1;
+                if (cell_lane) {
+                    pl.crow[lane] = (int16_t)(is_ch ? 3 * rank : R0p + total_rest + other);
+                    cpos[lane] = (uint8_t)(is_ch ? rank : n1 + other);
+                    if (is_ch) { pl.lst[rank] = (int16_t)my_lst; pl.nl[rank] = (int16_t)rest; }
+                }
+                // lane fi = face fi: the front it belongs to (its chosen cell), its slot there, its rows
+                const bool internal = face_lane && Ib != 0xFF;
+                const int key = !internal ? -1 : (((chosen >> Ia) & 1ull) ? Ia : (((chosen >> Ib) & 1ull) ? Ib : -1));
+                int slot_in_front = 0;
+                for (unsigned long long rem = chosen; rem; rem &= rem - 1ull) {
+                    const int c = __ffsll((long long)rem) - 1;
+                    const unsigned long long mm = __ballot(key == c);
+                    if (key == c) slot_in_front = __popcll(mm & below);
+                }
+                const int key_lst = __shfl(my_lst, key >= 0 ? key : 0), key_rank = __shfl(rank, key >= 0 ? key : 0);
+                const unsigned long long m_free = __ballot(internal && key < 0), m_neu = __ballot(face_lane && !internal && is_neu);
+                const int base_free = R0p + total_rest + n_other, base_neu = base_free + 3 * __popcll(m_free);
+                if (face_lane) {
+                    int16_t *fr = pl.frow + 3 * lane;
+                    if (internal && key >= 0) {
+                        if (slot_in_front == 0) {
+                            fr[0] = (int16_t)(3 * key_rank + 1); fr[1] = (int16_t)(3 * key_rank + 2); fr[2] = (int16_t)key_lst;
+                        } else {
+                            const int base = key_lst + 1 + 3 * (slot_in_front - 1);
+                            fr[0] = (int16_t)base; fr[1] = (int16_t)(base + 1); fr[2] = (int16_t)(base + 2);
+                        }
+                    } else if (internal) {
+                        const int base = base_free + 3 * __popcll(m_free & below);
+                        fr[0] = (int16_t)base; fr[1] = (int16_t)(base + 1); fr[2] = (int16_t)(base + 2);
+                    } else if (is_neu) {
+                        fr[0] = (int16_t)(base_neu + __popcll(m_neu & below));
+                    }
+                }
+                if (lane == 0) *n1_word = n1;
             }
             group_sync<NW>();
             // ---- assembly through the plan's row / column maps ----------------------------------------------------------
@@ -543,7 +582,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                         double eta = 0.0;
                         eta = da > eta ? da : eta;
                         eta = db > eta ? db : eta;
-                        const double tj = pow(sqrt(U0 * U0 + U1 * U1 + U2 * U2), -eta);
+                        const double tj = glsmath::face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
                         const double *Ka = g.perm + 9 * (size_t)ca, *Kb = g.perm + 9 * (size_t)cb;
                         double *ra = s.A + (size_t)(3 * cpos[Ia]) * ld, *rb = s.A + (size_t)(3 * cpos[Ib]) * ld;
                         const int r0 = fr[0], r1 = fr[1], r2 = fr[2];   // rows: K N, T1, tau T2
@@ -601,7 +640,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                     double eta = 0.0;
                     eta = da > eta ? da : eta;
                     eta = db > eta ? db : eta;
-                    const double tj = pow(sqrt(U0 * U0 + U1 * U1 + U2 * U2), -eta);
+                    const double tj = glsmath::face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
                     const double *Ka = g.perm + 9 * (size_t)ca, *Kb = g.perm + 9 * (size_t)cb;
                     int Ia = 0, Ib = 0;
                     for (int q = 0; q < ne; ++q) {
@@ -643,7 +682,8 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
         if (SPARSE) {
             const int n1 = ufirst(*n1_word);
             R0 = 3 * n1;
-            for (int rk = wave; rk < n1; rk += NW) front_qr<CS>(s, rk, pl.lst[rk], pl.nl[rk], sing);
+            for (int rk = wave; rk < n1; rk += NW)
+                if (front_qr<CS>(s, rk, pl.lst[rk], pl.nl[rk])) *sing = 1;
             group_sync<NW>();
         }
 
@@ -698,14 +738,26 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                 ct[q] = i < n - 1 ? s.A[(n - 1) * ld + i] : 0.0;
             }
             double *y = s.aux, *wrow = s.aux + n;
-            for (int k = n - 2; k >= 0; --k) {
-                const int ks = k >> 6, kl = k & 63;
-                double col[CS];
-                double rkk = 1.0, ck = 0.0;
+            // column k of R is read one step ahead of its use: the loop is a chain of LDS latencies otherwise
+            double coln[CS];
+            auto load_col = [&](int k, double (&c)[CS]) {
+                const int ks = k >> 6;
 #pragma unroll
                 for (int q = 0; q < CS; ++q) {
                     const int i = lane + 64 * q;
-                    col[q] = (q <= ks && i <= k) ? s.A[k * ld + i] : 0.0;
+                    c[q] = (q <= ks && i <= k) ? s.A[k * ld + i] : 0.0;
+                }
+            };
+            load_col(n - 2, coln);
+            for (int k = n - 2; k >= 0; --k) {
+                const int ks = k >> 6, kl = k & 63;
+                double col[CS];
+#pragma unroll
+                for (int q = 0; q < CS; ++q) col[q] = coln[q];
+                if (k > 0) load_col(k - 1, coln);
+                double rkk = 1.0, ck = 0.0;
+#pragma unroll
+                for (int q = 0; q < CS; ++q) {
                     if (q == ks) {
                         rkk = readlane_f64(col[q], kl);
                         ck = readlane_f64(ct[q], kl);
