@@ -6,9 +6,9 @@ import ninpol_amd
 from ninpol_amd import mesh as M
 cases = {"tet40": lambda: M.tet_mesh(40, jitter=0.1), "wedge60": lambda: M.wedge_mesh(60, jitter=0.05),
          "mixed": lambda: M.mixed_mesh(100, 60, 60, jitter=0.1), "hex100": lambda: M.hex_mesh(100, jitter=0.15),
-         "hex80m": lambda: M.hex_mesh(432, jitter=0.15),
+         "hex216": lambda: M.hex_mesh(216, jitter=0.15), "hex80m": lambda: M.hex_mesh(432, jitter=0.15),
          "mixed10m": lambda: M.mixed_mesh(200, 120, 120, jitter=0.1), "tet10m": lambda: M.tet_mesh(119, jitter=0.1)}
-for name in (sys.argv[1:] or [c for c in cases if not c.endswith(("10m", "80m"))]):
+for name in (sys.argv[1:] or [c for c in cases if not c.endswith(("10m", "80m", "216"))]):
     m = cases[name](); M.attach_fields(m, "u", perm="ALH")
     I = ninpol_amd.Interpolator(grid_build=os.environ.get("NIN_GRID_BUILD", "host")); t0 = time.time(); I.load_mesh(mesh_obj=m); print(f"{name}: load_mesh {time.time() - t0:.2f} s")
     st = torch.cuda.current_stream()
