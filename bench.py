@@ -151,17 +151,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    def all_gather_into(out_t, in_t):
-        if rehearsal:
-            o = torch.empty(out_t.shape, dtype=out_t.dtype)
-            dist.all_gather_into_tensor(o, in_t.cpu())
-            out_t.copy_(o)
-        else:
-            dist.all_gather_into_tensor(out_t, in_t)
-
     import ninpol_amd
     from ninpol_amd import mesh as M
-    from ninpol_amd.partition import node_block
+    from ninpol_amd.partition import ShardedInterpolator, node_block
 
     n = args.n
     nz_global = n * world
@@ -175,82 +167,57 @@ def main():
     # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers; the host grid build is OpenMP code, so give
     # every rank its share of the host cores explicitly (setup only, outside the timed region)
     host_threads = max(1, (os.cpu_count() or 1) // world) if world > 1 else 0
-    I = ninpol_amd.Interpolator(device=local_rank, num_threads=host_threads, grid_build=args.grid_build)
-    I.load_mesh(mesh_obj=mesh)
-    t_load = time.time() - t0
     t_load_dev = None
-    if world == 1 and not args.no_extras and args.grid_build == "host":
-        # context: the same load_mesh with the connectivity built by HIP kernels on the GPU
-        t0 = time.time()
-        I2 = ninpol_amd.Interpolator(device=local_rank, grid_build="device")
-        I2.load_mesh(mesh_obj=mesh)
-        t_load_dev = time.time() - t0
-        del I2
+    if world > 1:
+        # the library's multi-GPU path (ninpol_amd/partition.py): slab loader -- no rank holds the whole mesh --,
+        # device-resident triplets, columns / counts gathered once, values + Neumann array gathered per step
+        S = ShardedInterpolator(device=local_rank, comm_on_host=rehearsal, grid_build=args.grid_build,
+                                num_threads=host_threads)
+        S.load_shard(mesh, node_off, cell_off, (own_lo, own_hi), (n + 1) * (n + 1) * (nz_global + 1), n * n * nz_global)
+        I = S.local
+        t_load = time.time() - t0
+    else:
+        I = ninpol_amd.Interpolator(device=local_rank, num_threads=host_threads, grid_build=args.grid_build)
+        I.load_mesh(mesh_obj=mesh)
+        t_load = time.time() - t0
+        if not args.no_extras and args.grid_build == "host":
+            # context: the same load_mesh with the connectivity built by HIP kernels on the GPU
+            t0 = time.time()
+            I2 = ninpol_amd.Interpolator(device=local_rank, grid_build="device")
+            I2.load_mesh(mesh_obj=mesh)
+            t_load_dev = time.time() - t0
+            del I2
     del mesh
     g = I.grid
     t0 = time.time()
-    plan = I.device_plan("u", args.method)
+    if world > 1:
+        splan = S.device_plan("u", args.method)
+        plan = splan.plan
+    else:
+        plan = I.device_plan("u", args.method)
     t_push = time.time() - t0
     P_loc, n_owned = g.n_points, own_hi - own_lo
-    esup_ptr = g.esup_ptr
-    eb, ee = int(esup_ptr[own_lo]), int(esup_ptr[own_hi])
 
     stream = torch.cuda.current_stream()
-    counts_own = torch.from_numpy(np.diff(esup_ptr[own_lo:own_hi + 1]).astype(np.int32)).to(dev)
-    if world > 1:
-        # static parts of the triplets, global ids; padded so that every rank sends the same length
-        lens = torch.tensor([ee - eb, n_owned], dtype=torch.int64, device="cpu" if rehearsal else dev)
-        all_lens = [torch.empty_like(lens) for _ in range(world)]
-        dist.all_gather(all_lens, lens)
-        all_lens = torch.stack(all_lens).cpu().numpy()
-        mx_nnz, mx_rows = int(all_lens[:, 0].max()), int(all_lens[:, 1].max())
-        cols_pad = torch.zeros(mx_nnz, dtype=torch.int32, device=dev)
-        cols_pad[:ee - eb] = torch.from_numpy((g.esup[eb:ee] + cell_off).astype(np.int32)).to(dev)
-        cnt_pad = torch.zeros(mx_rows, dtype=torch.int32, device=dev)
-        cnt_pad[:n_owned] = counts_own
-        g_vals = torch.empty(world * mx_nnz, dtype=torch.float64, device=dev)
-        g_cols = torch.empty(world * mx_nnz, dtype=torch.int32, device=dev)
-        g_cnt = torch.empty(world * mx_rows, dtype=torch.int32, device=dev)
-    else:
-        mx_nnz = ee - eb
-    # two output buffers: the all-gather of step i runs (on RCCL's stream) under the kernel of step i + 1
-    n_buf = 2 if world > 1 else 1
-    outs = [torch.empty(max(plan.nnz, eb + mx_nnz), dtype=torch.float64, device=dev) for _ in range(n_buf)]
-    out = outs[0]
-    nws = torch.empty(P_loc, dtype=torch.float64, device=dev)
-    pending = [None] * n_buf      # outstanding collectives reading outs[b]
-    step_no = [0]
+    if world == 1:
+        out = torch.empty(plan.nnz, dtype=torch.float64, device=dev)
+        nws = torch.empty(P_loc, dtype=torch.float64, device=dev)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def drain(b):
-        if pending[b] is not None:
-            for w in pending[b]:
-                w.wait()          # current stream waits for the collective; the host does not block
-            pending[b] = None
-
     def step(i=None):
-        b = step_no[0] % n_buf
-        step_no[0] += 1
-        drain(b)                  # the buffer (and the gather targets) of two steps ago must have been delivered
+        if world > 1:   # kernel + the single exchange step of the path, asynchronous (two rotating buffer sets)
+            splan.step(ev[i] if i is not None else None)
+            return
         if i is not None:
             ev[i][0].record(stream)
-        plan.launch(outs[b].data_ptr(), nws.data_ptr(), stream.cuda_stream, add_neumann=True)
+        plan.launch(out.data_ptr(), nws.data_ptr(), stream.cuda_stream, add_neumann=True)
         if i is not None:
             ev[i][1].record(stream)
-        if world > 1:   # the single exchange step of the path: (count, column, value) of every owned row
-            if rehearsal:
-                all_gather_into(g_vals, outs[b][eb:eb + mx_nnz])
-                all_gather_into(g_cols, cols_pad)
-                all_gather_into(g_cnt, cnt_pad)
-            else:
-                pending[b] = [dist.all_gather_into_tensor(g_vals, outs[b][eb:eb + mx_nnz], async_op=True),
-                              dist.all_gather_into_tensor(g_cols, cols_pad, async_op=True),
-                              dist.all_gather_into_tensor(g_cnt, cnt_pad, async_op=True)]
 
     def drain_all():
-        for b in range(n_buf):
-            drain(b)
+        if world > 1:
+            splan.drain_all()
 
     for _ in range(args.warmup):
         step()
@@ -291,15 +258,12 @@ def main():
         nw = torch.empty(pw.n_points, dtype=torch.float64, device=dev)
         pw.launch(ow.data_ptr(), nw.data_ptr(), stream.cuda_stream, add_neumann=True)
         torch.cuda.synchronize()
-        vals, cols, cnts = [], [], []
-        for r in range(world):
-            vals.append(g_vals[r * mx_nnz:r * mx_nnz + int(all_lens[r, 0])])
-            cols.append(g_cols[r * mx_nnz:r * mx_nnz + int(all_lens[r, 0])])
-            cnts.append(g_cnt[r * mx_rows:r * mx_rows + int(all_lens[r, 1])])
-        vals, cols, cnts = torch.cat(vals).cpu().numpy(), torch.cat(cols).cpu().numpy(), torch.cat(cnts).cpu().numpy()
+        b_last = (splan.n_steps - 1) % 2
+        cat = lambda t, which: torch.cat(splan.pieces(t, which)).cpu().numpy()
         gw = Iw.grid
-        check = bool(np.array_equal(cnts, np.diff(gw.esup_ptr)) and np.array_equal(cols, gw.esup)
-                     and np.array_equal(vals, ow.cpu().numpy()))
+        check = bool(np.array_equal(cat(splan.counts, 1), np.diff(gw.esup_ptr)) and np.array_equal(cat(splan.cols, 0), gw.esup)
+                     and np.array_equal(cat(splan.vals[b_last], 0), ow.cpu().numpy())
+                     and np.array_equal(cat(splan.neumann[b_last], 1), nw.cpu().numpy()))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -336,8 +300,9 @@ def main():
             "config": {"workload": f"{args.method.upper()} interpolate() weights, {n}x{n}x{n * world} hexahedra "
                                    f"({n ** 3 * world} cells, {total_nodes} nodes), jitter {args.jitter}, ALH permeability, "
                                    "all-Dirichlet boundary; inputs resident in HBM, output CSR values on device"
-                                   + ("; + RCCL all-gather of (count, column, value) per step, overlapped with the next "
-                                      "step's kernel (two output buffers)" if world > 1 else ""),
+                                   + ("; + RCCL all-gather of the (count, column, value) triplets and the Neumann array: columns "
+                                      "and counts once per mesh, values per step, overlapped with the next step's kernel "
+                                      "(ShardedPlan, two buffer sets)" if world > 1 else ""),
                        "cells_per_gpu": n ** 3, "nodes_total": total_nodes, "nnz_esup_rank0": plan.nnz,
                        "parallelism": f"node-block shards x{world}, neighbour cells replicated" if world > 1 else "single GPU"},
             "roofline": roof,
@@ -375,7 +340,7 @@ def main():
                 line[meth] = {"kernel_ms": round(ms, 4), "Mnodes_per_s": round(P_loc / ms / 1e3, 1),
                               "achieved_GBps": round(p2.algorithmic_bytes / (ms * 1e-3) / 1e9, 1),
                               "frac_hbm": round(p2.algorithmic_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            del out, outs, nws
+            del out, nws
             torch.cuda.empty_cache()
             t0 = time.time()
             W, _ = I.interpolate("u", args.method)

@@ -11,7 +11,9 @@ shards with no exchange during compute:
     rows it sees in the whole mesh, in the same order: results are bit-identical to a single-GPU run;
   * after the kernels, ONE all-gather with per-rank counts (allgatherv) reassembles the rows:
     per owned node its entry count, per entry (global column int32, value float64).  Over RCCL the
-    uneven sizes are handled by exchanging the counts first and padding to the largest shard.
+    uneven sizes are handled by exchanging the counts first and padding to the largest shard.  Everything
+    stays on the device (ShardedPlan): columns and counts are gathered once per mesh, a step gathers the
+    values and the Neumann array, asynchronously, under the next step's kernel.
 
 torch.distributed is plumbing only (process group + the collective); backend "nccl" is RCCL over xGMI
 on the GPU box and "gloo" in the CPU tests.
@@ -83,55 +85,202 @@ def allgatherv(tensors, counts_hint=None, group=None):
     return out
 
 
+class ShardedPlan:
+    """Device-resident `interpolate(variable, method)` over the process group: this rank's kernel writes its node
+    block's CSR values, ONE all-gather per step reassembles the (count, column, value) triplets + the Neumann array on
+    every rank.  Columns and counts do not depend on the step (they are the esup rows of the owned nodes, global cell
+    ids): they are gathered once, here; a step moves 8 B per entry + 8 B per row.
+
+    Shards are padded to the longest (RCCL has no allgatherv); rank r's piece of a gathered tensor `t` is
+    t[r * mx : r * mx + lens[r]].  Two output / gather buffer sets rotate: `step()` returns at once, the gather of step
+    i runs (on the collective's stream) under the kernel of step i + 1, and the buffers of a step stay valid until the
+    step after next starts."""
+
+    def __init__(self, sharded, variable, method):
+        import torch
+        import torch.distributed as dist
+        S = self.S = sharded
+        self.method = method
+        self.plan = S.local.device_plan(variable, method)
+        g = S.local.grid
+        esup_ptr = np.asarray(g.esup_ptr)
+        lo, hi = S.own_lo, S.own_hi
+        self.eb, self.ee = int(esup_ptr[lo]), int(esup_ptr[hi])
+        self.n_owned = hi - lo
+        dev, cdev = S.torch_device, S.comm_device
+        self.dev = dev
+        lens = torch.tensor([self.ee - self.eb, self.n_owned], dtype=torch.int64, device=cdev)
+        all_lens = [torch.empty_like(lens) for _ in range(S.world)]
+        dist.all_gather(all_lens, lens, group=S.group)
+        self.lens = torch.stack(all_lens).cpu().numpy()          # (world, 2): entries, rows per rank
+        self.mx_nnz, self.mx_rows = int(self.lens[:, 0].max()), int(self.lens[:, 1].max())
+        # static parts, global ids, padded, gathered once
+        cols = S.global_cells(np.asarray(g.esup)[self.eb:self.ee]).astype(np.int32)
+        cols_pad = torch.zeros(self.mx_nnz, dtype=torch.int32, device=dev)
+        cols_pad[:self.ee - self.eb] = torch.from_numpy(np.ascontiguousarray(cols)).to(dev)
+        cnt_pad = torch.zeros(self.mx_rows, dtype=torch.int32, device=dev)
+        cnt_pad[:self.n_owned] = torch.from_numpy(np.diff(esup_ptr[lo:hi + 1]).astype(np.int32)).to(dev)
+        self.cols = torch.empty(S.world * self.mx_nnz, dtype=torch.int32, device=dev)
+        self.counts = torch.empty(S.world * self.mx_rows, dtype=torch.int32, device=dev)
+        S._gather(self.cols, cols_pad)
+        S._gather(self.counts, cnt_pad)
+        n_out = max(int(self.plan.nnz), self.eb + self.mx_nnz)   # the padded send window must stay inside the buffer
+        n_nws = max(int(self.plan.n_points), lo + self.mx_rows)
+        self.out = [torch.zeros(n_out, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.nws = [torch.zeros(n_nws, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.vals = [torch.empty(S.world * self.mx_nnz, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.neumann = [torch.empty(S.world * self.mx_rows, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.pending = [None, None]
+        self.n_steps = 0
+
+    def drain(self, b):
+        if self.pending[b] is not None:
+            for w in self.pending[b]:
+                w.wait()          # the current stream waits for the collective; the host does not block
+            self.pending[b] = None
+
+    def drain_all(self):
+        self.drain(0)
+        self.drain(1)
+
+    def step(self, events=None):
+        """One pass of the hot path over this rank's shard + the exchange; returns the buffer set it went to.
+        events: optional (start, end) torch.cuda.Event pair recorded around the kernel launches (bench.py)."""
+        S = self.S
+        b = self.n_steps % 2
+        self.n_steps += 1
+        self.drain(b)             # the gather that last read this buffer set must have been delivered
+        if events is not None:
+            events[0].record()
+        S._launch(self.plan, self.out[b], self.nws[b])
+        if events is not None:
+            events[1].record()
+        lo = S.own_lo
+        self.pending[b] = [S._gather(self.vals[b], self.out[b][self.eb:self.eb + self.mx_nnz], async_op=True),
+                           S._gather(self.neumann[b], self.nws[b][lo:lo + self.mx_rows], async_op=True)]
+        self.pending[b] = [w for w in self.pending[b] if w is not None] or None
+        return b
+
+    def pieces(self, t, which):
+        """Per-rank pieces of a gathered tensor (which: 0 = per entry, 1 = per row)."""
+        mx = self.mx_nnz if which == 0 else self.mx_rows
+        return [t[r * mx:r * mx + int(self.lens[r, which])] for r in range(self.S.world)]
+
+
 class ShardedInterpolator:
-    """`interpolate()` over a process group: every rank loads the same mesh object, computes the rows
-    of its node block on its own GPU and receives the whole (n_points x n_elems) matrix.
+    """`interpolate()` over a process group: rank r holds the node block [P r / W, P (r+1) / W) of the mesh plus the
+    cells around it, computes those rows on its own GPU and receives the whole (n_points x n_elems) matrix.
 
-    make_interpolator: factory for the per-rank compute object (default: ninpol_amd.Interpolator on
-    this rank's GPU).  The CPU tests inject the oracle here; the product path never does."""
+    Two ways in: `load_mesh(mesh_obj)` -- every rank is handed the same whole mesh and cuts its block out of it -- and
+    `load_shard(...)` -- every rank brings only its own shard (a slab generated or read per rank: no rank ever holds the
+    whole mesh; this is what bench.py --gpus N uses).
 
-    def __init__(self, group=None, device=None, make_interpolator=None, comm_on_host=False, grid_build="host"):
-        """device: this rank's GPU (None: the injected compute object runs on the host -- CPU tests only).
+    make_interpolator: factory for the per-rank compute object (default: ninpol_amd.Interpolator on this rank's GPU).
+    The CPU tests inject an oracle-backed object here; the product path never does."""
+
+    def __init__(self, group=None, device=None, make_interpolator=None, comm_on_host=False, grid_build="host",
+                 num_threads=0):
+        """device: this rank's GPU (None: the injected compute object works on host tensors -- CPU tests only).
         comm_on_host: stage the all-gather through host tensors (a gloo group next to GPU compute, e.g. several
         ranks rehearsing on one GPU); default: the collective runs on the compute device (backend nccl = RCCL)."""
+        import torch
         import torch.distributed as dist
         self.comm_on_host = bool(comm_on_host)
         self.grid_build = grid_build
+        self.num_threads = num_threads
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = device
+        self.torch_device = torch.device("cpu") if device is None else torch.device("cuda", device)
+        self.comm_device = torch.device("cpu") if (device is None or self.comm_on_host) else self.torch_device
         self._make = make_interpolator
         self.local = None
+        self._plans = {}
 
+    # ---- loading ------------------------------------------------------------------------------------------------
     def load_mesh(self, mesh_obj):
-        self.n_points = int(np.asarray(mesh_obj.points).shape[0])
-        self.lo, self.hi = node_block(self.n_points, self.rank, self.world)
-        sub, self.point_ids, self.cell_ids, self.owned = extract_submesh(mesh_obj, self.lo, self.hi)
+        n_points = int(np.asarray(mesh_obj.points).shape[0])
+        lo, hi = node_block(n_points, self.rank, self.world)
+        sub, point_ids, cell_ids, owned = extract_submesh(mesh_obj, lo, hi)
         dim = T.mesh_dimension([b.type for b in mesh_obj.cells])
-        self.n_elems = int(sum(len(b.data) for b in mesh_obj.cells if b.type in T.TYPES_PER_DIMENSION[dim]))
+        n_elems = int(sum(len(b.data) for b in mesh_obj.cells if b.type in T.TYPES_PER_DIMENSION[dim]))
+        assert len(owned) == hi - lo and (len(owned) == 0 or np.array_equal(owned, np.arange(owned[0], owned[0] + len(owned))))
+        self.load_shard(sub, point_ids, cell_ids, (int(owned[0]) if len(owned) else 0, int(owned[0]) + len(owned) if len(owned) else 0),
+                        n_points, n_elems)
+
+    def load_shard(self, shard_mesh, point_ids, cell_ids, owned, n_points, n_elems):
+        """shard_mesh: this rank's cells and the points they use, local numbering monotone in the global one.
+        point_ids / cell_ids: local -> global ids, as arrays or -- for a contiguous slab -- as integer offsets.
+        owned: the LOCAL node range (lo, hi) this rank owns (globally: a contiguous block; blocks of the ranks tile
+        [0, n_points) in rank order).  n_points / n_elems: of the whole mesh."""
+        self.n_points, self.n_elems = int(n_points), int(n_elems)
+        self.point_ids, self.cell_ids = point_ids, cell_ids
+        self.own_lo, self.own_hi = int(owned[0]), int(owned[1])
+        self.lo = int(self.global_points(np.array([self.own_lo]))[0]) if self.own_hi > self.own_lo else 0
+        self.hi = self.lo + (self.own_hi - self.own_lo)
         if self._make is None:
             from .interpolator import Interpolator
-            self.local = Interpolator(device=self.device if self.device is not None else 0, grid_build=self.grid_build)
+            self.local = Interpolator(device=self.device if self.device is not None else 0, grid_build=self.grid_build,
+                                      num_threads=self.num_threads)
         else:
             self.local = self._make()
-        self.local.load_mesh(mesh_obj=sub)
+        self.local.load_mesh(mesh_obj=shard_mesh)
+        self._plans = {}
+
+    def global_cells(self, local_ids):
+        return local_ids + self.cell_ids if np.isscalar(self.cell_ids) else np.asarray(self.cell_ids)[local_ids]
+
+    def global_points(self, local_ids):
+        return local_ids + self.point_ids if np.isscalar(self.point_ids) else np.asarray(self.point_ids)[local_ids]
+
+    # ---- the exchange ---------------------------------------------------------------------------------------------
+    def _gather(self, out_t, in_t, async_op=False):
+        import torch
+        import torch.distributed as dist
+        if self.comm_device != self.torch_device:      # rehearsal: gloo through host copies, synchronous
+            o = torch.empty(out_t.shape, dtype=out_t.dtype)
+            dist.all_gather_into_tensor(o, in_t.cpu().contiguous(), group=self.group)
+            out_t.copy_(o)
+            return None
+        return dist.all_gather_into_tensor(out_t, in_t, group=self.group, async_op=async_op) if async_op else \
+            dist.all_gather_into_tensor(out_t, in_t, group=self.group)
+
+    def _launch(self, plan, out_t, nws_t):
+        if hasattr(plan, "launch_tensors"):            # injected compute object (CPU tests)
+            plan.launch_tensors(out_t, nws_t)
+            return
+        import torch
+        plan.launch(out_t.data_ptr(), nws_t.data_ptr(), torch.cuda.current_stream(self.torch_device).cuda_stream,
+                    add_neumann=True)
+
+    def device_plan(self, variable, method):
+        key = (variable, method)
+        if key not in self._plans:
+            self._plans[key] = ShardedPlan(self, variable, method)
+        return self._plans[key]
+
+    def interpolate_device(self, variable, method):
+        """One step, waited for.  Returns (plan, b): the gathered triplets are plan.counts / plan.cols (static) and
+        plan.vals[b] / plan.neumann[b], padded per rank -- see ShardedPlan.pieces()."""
+        import torch
+        sp_ = self.device_plan(variable, method)
+        b = sp_.step()
+        sp_.drain(b)
+        if self.torch_device.type == "cuda":
+            torch.cuda.synchronize(self.torch_device)
+        return sp_, b
 
     def interpolate(self, variable, method):
+        """The reference's result tuple, assembled from the gathered triplets: (csr_matrix (n_points x n_elems),
+        neumann_ws), zeros eliminated as interpolator.pyx:622-624 does."""
         import torch
-        W, nws = self.local.interpolate(variable, method)          # local (P_loc x E_loc), zeros eliminated
-        W = W.tocsr()[self.owned]                                  # rows of the owned block, ascending
-        cols = self.cell_ids[W.indices].astype(np.int32)           # local -> global cell id
-        dev = torch.device("cpu") if (self.device is None or self.comm_on_host) else torch.device("cuda", self.device)
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        row_nnz = np.diff(W.indptr).astype(np.int32)
-        pieces = allgatherv([t(W.data), t(cols)], group=self.group)
-        rows = allgatherv([t(row_nnz), t(np.ascontiguousarray(nws[self.owned]))], group=self.group)
-        data = torch.cat(pieces[0]).cpu().numpy()
-        indices = torch.cat(pieces[1]).cpu().numpy()
-        counts = torch.cat(rows[0]).cpu().numpy().astype(np.int64)
-        neumann = torch.cat(rows[1]).cpu().numpy()
+        sp_, b = self.interpolate_device(variable, method)
+        cat = lambda t, which: torch.cat(sp_.pieces(t, which)).cpu().numpy()
+        data, indices = cat(sp_.vals[b], 0), cat(sp_.cols, 0)
+        counts, neumann = cat(sp_.counts, 1).astype(np.int64), cat(sp_.neumann[b], 1)
         indptr = np.concatenate([[0], np.cumsum(counts)])
         idx_t = np.int32 if max(len(data), self.n_elems, self.n_points) < np.iinfo(np.int32).max else np.int64
         full = sp.csr_matrix((data, indices.astype(idx_t), indptr.astype(idx_t)), shape=(self.n_points, self.n_elems))
+        full.eliminate_zeros()
         return full, neumann

@@ -1,6 +1,9 @@
 """N > 1 with the REAL kernels: two ranks share the one GPU of the box (at most 6 processes may), each computes its
-node block with the HIP path, the all-gather runs over gloo through host tensors.  The gathered matrix must be
-bit-identical to the single-process GPU result -- the property the RCCL path relies on."""
+node block with the HIP path through ShardedPlan -- the code bench.py --gpus N runs: device-resident triplets,
+static columns / counts gathered once, rotating buffer sets -- and the all-gather goes over gloo through host tensors
+(comm_on_host; on the 8-GPU node it is RCCL on the device tensors).  The gathered matrix must be bit-identical to the
+single-process GPU result -- the property the RCCL path relies on.  "slab": each rank generates only its own
+slab (load_shard), as the bench does; no rank holds the whole mesh."""
 import os
 import socket
 import sys
@@ -24,8 +27,11 @@ def _free_port():
     return p
 
 
+SLAB = (9, 8, 10)
+
+
 def _make_mesh(kind):
-    m = M.mixed_mesh(9, 5, 5, jitter=0.1, seed=3) if kind == "mixed" else M.hex_mesh(9, 8, 10, jitter=0.15, seed=1)
+    m = M.mixed_mesh(9, 5, 5, jitter=0.1, seed=3) if kind == "mixed" else M.hex_mesh(*SLAB, jitter=0.15, seed=1)
     M.attach_fields(m, "u", perm="ALH", neumann_plane=(2, 0.0), seed=5)
     return m
 
@@ -40,16 +46,26 @@ def _worker(rank, world, port, kind, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         S = ShardedInterpolator(device=0, comm_on_host=True, grid_build=("host", "device")[rank % 2])
-        S.load_mesh(_make_mesh(kind))
+        if kind == "slab":
+            from ninpol_amd.partition import node_block
+            plane_lo, plane_hi = node_block(SLAB[2] + 1, rank, world)
+            sub, node_off, cell_off, own_lo, own_hi = M.hex_slab(*SLAB, plane_lo, plane_hi, jitter=0.15, seed=1)
+            M.attach_fields(sub, "u", perm="ALH", neumann_plane=(2, 0.0), seed=5)
+            S.load_shard(sub, node_off, cell_off, (own_lo, own_hi), (SLAB[0] + 1) * (SLAB[1] + 1) * (SLAB[2] + 1),
+                         SLAB[0] * SLAB[1] * SLAB[2])
+        else:
+            S.load_mesh(_make_mesh(kind))
         for meth in ("idw", "ls", "gls"):
             W, nws = S.interpolate("u", meth)
+            W2, nws2 = S.interpolate("u", meth)   # second step: the other buffer set of the rotation
+            assert np.array_equal(W.data, W2.data, equal_nan=True) and np.array_equal(nws, nws2, equal_nan=True)
             if rank == 0:
                 np.savez(os.path.join(out_dir, f"{kind}_{meth}.npz"), indptr=W.indptr, indices=W.indices, data=W.data, nws=nws)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["hex", "mixed"])
+@pytest.mark.parametrize("kind", ["hex", "mixed", "slab"])
 def test_two_ranks_on_one_gpu_match_single_process(kind, tmp_path):
     import ninpol_amd
     world = 2
@@ -62,3 +78,41 @@ def test_two_ranks_on_one_gpu_match_single_process(kind, tmp_path):
         assert np.array_equal(z["indptr"], W.indptr) and np.array_equal(z["indices"], W.indices), meth
         assert np.array_equal(z["data"], W.data, equal_nan=True), meth
         assert np.array_equal(z["nws"], nws, equal_nan=True), meth
+
+
+def _rccl_worker(rank, port, out_dir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ninpol_amd.partition import ShardedInterpolator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        S = ShardedInterpolator(device=0, grid_build="device")     # the collectives run on the device tensors (RCCL)
+        S.load_mesh(_make_mesh("hex"))
+        sp = S.device_plan("u", "gls")
+        for _ in range(5):                                         # asynchronous steps over both buffer sets
+            b = sp.step()
+        sp.drain_all()
+        torch.cuda.synchronize()
+        W, nws = S.interpolate("u", "gls")
+        np.savez(os.path.join(out_dir, "rccl.npz"), indptr=W.indptr, indices=W.indices, data=W.data, nws=nws,
+                 vals=torch.cat(sp.pieces(sp.vals[b], 0)).cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_one_rank_group(tmp_path):
+    """The exchange exactly as the 8-GPU run issues it -- backend nccl (= RCCL), device tensors, async_op, both buffer
+    sets -- on the one GPU this box has (a one-rank group): the call pattern and stream ordering, not the scaling."""
+    import ninpol_amd
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    I = ninpol_amd.Interpolator()
+    I.load_mesh(mesh_obj=_make_mesh("hex"))
+    W, nws = I.interpolate("u", "gls")
+    z = np.load(os.path.join(str(tmp_path), "rccl.npz"))
+    assert np.array_equal(z["indptr"], W.indptr) and np.array_equal(z["indices"], W.indices)
+    assert np.array_equal(z["data"], W.data, equal_nan=True) and np.array_equal(z["nws"], nws, equal_nan=True)
