@@ -145,6 +145,15 @@ int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *
  * node_values [n_points] (0 on the empty rows of Dirichlet nodes), neumann_ws [n_points]. */
 int nin_apply_host(nin_grid *g, int method, const double *u_cells, double *node_values, double *neumann_ws);
 
+/* The same for n_fields cell fields at once -- the weights are computed ONCE and applied to every field (the
+ * reference's callers loop `weights.dot(u)` over their variables with one matrix, tests/utils/analytical.py:236):
+ * u_cells [n_fields][n_elems] -> node_values [n_fields][n_points], row-major.  _device: DEVICE pointers, asynchronous
+ * on `stream` (hipStream_t, NULL = default); _fields_host: host pointers, synchronous. */
+int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t n_fields, double *dev_node_values,
+                     double *dev_neumann_ws, void *stream);
+int nin_apply_fields_host(nin_grid *g, int method, const double *u_cells, int32_t n_fields, double *node_values,
+                          double *neumann_ws);
+
 /* Algorithmic HBM bytes one nin_weights call moves for `method` over all nodes (DESIGN.md formula,
  * SURVEY 8d): used by bench.py for the roofline line. */
 int64_t nin_algorithmic_bytes(const nin_grid *g, int method);

@@ -618,28 +618,54 @@ int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *
     return rc;
 }
 
-int nin_apply_host(nin_grid *g, int method, const double *u_cells, double *node_values, double *neumann_ws) {
+int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t n_fields, double *dev_node_values,
+                     double *dev_neumann_ws, void *stream_) {
+    if (!g || !dev_u_cells || !dev_node_values || !dev_neumann_ws) return fail(NIN_EINVAL, "NULL argument");
+    if (n_fields < 1) return fail(NIN_EINVAL, "n_fields must be >= 1");
+    DeviceGrid &d = g->d;
+    if (d.device < 0 || d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
+    HIP_TRY(hipSetDevice(d.device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!d.apply_weights) {   // the weights of the last apply: one buffer per grid, allocated on first use
+        int rc = dev_alloc(d, &d.apply_weights, (size_t)std::max<int64_t>(d.nnz_e, 1));
+        if (rc) return rc;
+    }
+    // the weights are computed ONCE, whatever the number of fields (they depend on the mesh, the permeability and the
+    // Neumann flags only: the reference's callers do `weights.dot(u)` per field with the same matrix)
+    int rc = nin_weights_device(g, method, nullptr, 0, 1, d.apply_weights, dev_neumann_ws, stream_);
+    if (rc) return rc;
+    rc = n_fields == 1 ? launch_apply(d.v, d.apply_weights, dev_u_cells, dev_node_values, stream)
+                       : launch_apply_fields(d.v, d.apply_weights, dev_u_cells, n_fields, dev_node_values, stream);
+    if (rc) return fail(rc, "launch failed");
+    return NIN_OK;
+}
+
+int nin_apply_fields_host(nin_grid *g, int method, const double *u_cells, int32_t n_fields, double *node_values,
+                          double *neumann_ws) {
     if (!g || !u_cells || !node_values || !neumann_ws) return fail(NIN_EINVAL, "NULL argument");
+    if (n_fields < 1) return fail(NIN_EINVAL, "n_fields must be >= 1");
     DeviceGrid &d = g->d;
     if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
     HIP_TRY(hipSetDevice(d.device));
-    const size_t nb = (size_t)std::max<int64_t>(d.nnz_e, 1) * 8, pb = (size_t)g->h.n_points * 8, eb = (size_t)g->h.n_elems * 8;
-    double *dd = nullptr, *dn = nullptr, *du = nullptr, *dv = nullptr;
-    auto cleanup = [&]() { (void)hipFree(dd); (void)hipFree(dn); (void)hipFree(du); (void)hipFree(dv); };
+    const size_t pb = (size_t)g->h.n_points * 8, eb = (size_t)g->h.n_elems * 8;
+    double *dn = nullptr, *du = nullptr, *dv = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dn); (void)hipFree(du); (void)hipFree(dv); };
 #define TRY_A(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    TRY_A(hipMalloc((void **)&dd, nb));
     TRY_A(hipMalloc((void **)&dn, pb));
-    TRY_A(hipMalloc((void **)&du, eb));
-    TRY_A(hipMalloc((void **)&dv, pb));
-    TRY_A(hipMemcpy(du, u_cells, eb, hipMemcpyHostToDevice));
-    int rc = nin_weights_device(g, method, nullptr, 0, 1, dd, dn, nullptr);
-    if (!rc) rc = launch_apply(d.v, dd, du, dv, nullptr);
-    if (rc) { cleanup(); return rc < 0 && g_err.empty() ? fail(rc, "launch failed") : rc; }
-    TRY_A(hipMemcpy(node_values, dv, pb, hipMemcpyDeviceToHost));
+    TRY_A(hipMalloc((void **)&du, eb * n_fields));
+    TRY_A(hipMalloc((void **)&dv, pb * n_fields));
+    TRY_A(hipMemcpy(du, u_cells, eb * n_fields, hipMemcpyHostToDevice));
+    const int rc = nin_apply_device(g, method, du, n_fields, dv, dn, nullptr);
+    if (rc) { cleanup(); return rc; }
+    TRY_A(hipMemcpy(node_values, dv, pb * n_fields, hipMemcpyDeviceToHost));
     TRY_A(hipMemcpy(neumann_ws, dn, pb, hipMemcpyDeviceToHost));
 #undef TRY_A
     cleanup();
     return NIN_OK;
+}
+
+int nin_apply_host(nin_grid *g, int method, const double *u_cells, double *node_values, double *neumann_ws) {
+    return nin_apply_fields_host(g, method, u_cells, 1, node_values, neumann_ws);
 }
 
 int64_t nin_algorithmic_bytes(const nin_grid *g, int method) {

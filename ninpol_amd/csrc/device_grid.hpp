@@ -84,6 +84,7 @@ struct DeviceGrid {
     int64_t gls_scratch_stride = 0; // doubles per wave slot
     int32_t gls_scratch_slots = 0;
     int32_t *gls_queue = nullptr;   // [kGlsQueueInts]
+    double *apply_weights = nullptr;   // [nnz_e] weights of the last nin_apply_device (allocated on first use)
     bool gls_too_large = false;     // some node's system has more rows than the scratch kernel handles (1024)
 };
 

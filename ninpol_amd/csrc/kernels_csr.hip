@@ -52,6 +52,30 @@ __global__ __launch_bounds__(256) void nin_apply_kernel(GridView g, const double
     }
 }
 
+// The same for k cell fields at once (u: [k][n_elems], values: [k][n_points]): the weights of a row are read once per
+// group of four fields instead of once per field.
+__global__ __launch_bounds__(256) void nin_apply_fields_kernel(GridView g, const double *__restrict__ data,
+                                                               const double *__restrict__ u, int32_t k,
+                                                               double *__restrict__ values) {
+    const size_t E = (size_t)g.n_elems, P = (size_t)g.n_points;
+    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < g.n_points; p += gridDim.x * blockDim.x) {
+        const int32_t b = g.esup_ptr[p], e = g.esup_ptr[p + 1];
+        for (int32_t f0 = 0; f0 < k; f0 += 4) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int32_t q = b; q < e; ++q) {
+                const double w = data[q];
+                const size_t c = (size_t)g.esup[q];
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    if (f0 + f < k) acc[f] += w * u[(size_t)(f0 + f) * E + c];
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                if (f0 + f < k) values[(size_t)(f0 + f) * P + p] = acc[f];
+        }
+    }
+}
+
 int grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -72,6 +96,12 @@ int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr
 
 int launch_apply(const GridView &g, const double *data, const double *u, double *values, hipStream_t stream) {
     hipLaunchKernelGGL(nin_apply_kernel, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, u, values);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(nin_apply_fields_kernel, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, u, k, values);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

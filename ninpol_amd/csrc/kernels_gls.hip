@@ -100,15 +100,16 @@ __global__ __launch_bounds__(256) void nin_gls_wave_kernel(GridView g, const int
             n_if += __popcll(__ballot(internal));
         }
         const int n_bf = nf - n_if;
-        // Dirichlet boundary node (gls.pyx:165-166), or n_bface >= n_face (gls.pyx:266-267: the system
-        // stays empty and dgels returns an all-zero row n-1): zero row.
-        if (((fl & 1) && !is_neu) || n_if == 0) {
+        const int n = 3 * ne + 1;                              // columns, the last one is c
+        const int m = ne + 3 * n_if + (is_neu ? n_bf : 0);     // rows actually populated
+        // Dirichlet boundary node (gls.pyx:165-166), n_bface >= n_face (gls.pyx:266-267: the system stays empty and
+        // dgels returns an all-zero row n-1), or fewer rows than unknowns next to the node value: zero row -- the
+        // same rule as kernels_gls_block.hip, so a node gets the same answer whichever kernel its size class runs on.
+        if (((fl & 1) && !is_neu) || n_if == 0 || m < n - 1) {
             for (int i = lane; i < ne; i += 64) out[eb + i] = 0.0;
             if (lane == 0) nws[p] = 0.0;
             continue;
         }
-        const int n = 3 * ne + 1;                              // columns, the last one is c
-        const int m = ne + 3 * n_if + (is_neu ? n_bf : 0);     // rows actually populated
         const int ld = m;
         int32_t *cells = reinterpret_cast<int32_t *>(base);   // [ne] (padded to an even count)
         double *tau = base + ((ne + 1) >> 1);                  // [n]

@@ -42,6 +42,9 @@ int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr
                    double *vals, hipStream_t stream);
 
 int launch_apply(const GridView &g, const double *data, const double *u, double *values, hipStream_t stream);
+// k fields at once: u [k][n_elems], values [k][n_points]
+int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values,
+                        hipStream_t stream);
 
 // GLS launch plan (grid_device.hip): size class of every node (255 = the hex8 group kernel) and, per class, the
 // maxima of (bytes, rows, columns) as 3 * kGlsClasses unsigned 64-bit values; all DEVICE pointers

@@ -359,9 +359,11 @@ class Interpolator:
         return W, nws
 
     def apply(self, variable, method, values=None):
-        """Interpolate a cell field to the nodes on the device: `W.dot(u)` of the reference's callers
-        (tests/utils/analytical.py:236) without bringing W to the host.  `values`: cell array (default: the
-        cell variable `variable` itself).  Returns (node_values, neumann_ws); Dirichlet rows are 0."""
+        """Interpolate cell fields to the nodes on the device: `W.dot(u)` of the reference's callers
+        (tests/utils/analytical.py:236) without bringing W to the host.  `values`: one cell array (n_elems,) -- default:
+        the cell variable `variable` itself -- or k of them as (k, n_elems): the weights (which depend on `variable`
+        only through its Neumann flags) are computed once and applied to every field.  Returns (node_values,
+        neumann_ws), node_values shaped like `values` with n_points in place of n_elems; Dirichlet rows are 0."""
         if not self.is_grid_initialized:
             raise ValueError("Grid not initialized. Please load a mesh first.")
         if method not in self.supported_methods:
@@ -376,12 +378,13 @@ class Interpolator:
         if values is None:
             values = np.asarray(self.cells_data[self.variable_to_index["cells"][variable]])[:g.n_elems]
         u = np.ascontiguousarray(values, dtype=DTYPE_F)
-        if u.shape != (g.n_elems,):
-            raise ValueError(f"values must have shape ({g.n_elems},), not {u.shape}.")
+        if u.shape != (g.n_elems,) and not (u.ndim == 2 and u.shape[0] >= 1 and u.shape[1] == g.n_elems):
+            raise ValueError(f"values must have shape ({g.n_elems},) or (k, {g.n_elems}), not {u.shape}.")
         _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable)
-        out = np.empty(g.n_points, dtype=DTYPE_F)
+        k = 1 if u.ndim == 1 else u.shape[0]
+        out = np.empty(g.n_points if u.ndim == 1 else (k, g.n_points), dtype=DTYPE_F)
         nws = np.empty(g.n_points, dtype=DTYPE_F)
-        _lib.check(_lib.load().nin_apply_host(g._h, _lib.METHOD_ID[method], _ptr(u), _ptr(out), _ptr(nws)))
+        _lib.check(_lib.load().nin_apply_fields_host(g._h, _lib.METHOD_ID[method], _ptr(u), k, _ptr(out), _ptr(nws)))
         return out, nws
 
     def device_plan(self, variable, method):

@@ -84,6 +84,33 @@ def test_gpu_target_subset(oracle_lib):
         assert W.shape == (len(targets), I.grid.n_elems)
 
 
+def test_gpu_target_subset_spans_gls_classes(oracle_lib):
+    """A target list that hits every GLS launch class of a mixed mesh in ONE call -- cube nodes (the multifrontal
+    kernel, which also needs its descriptors built for the list), boundary nodes (one wave per node), pyramid / tet
+    transition and Kuhn-tet nodes (2 and 4 waves per node): the per-class device lists share one allocation that must
+    outlive all the launches (the bug fixed in 3f9bef5), in an order that is not the node order."""
+    mesh = M.mixed_mesh(12, 6, 6, jitter=0.1, seed=6)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=2)
+    o = oracle_lib.OracleInterpolator("port", threads=4)
+    o.load_mesh(mesh)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    ne = np.diff(np.asarray(I.grid.esup_ptr))
+    bp = np.asarray(I.grid.boundary_points).astype(bool)
+    rng = np.random.default_rng(1)
+    picks = []
+    for sel in (~bp & (ne == 8), ~bp & (ne == 24), ~bp & (ne > 8) & (ne < 24), ~bp & (ne > 24), bp):
+        ids = np.nonzero(sel)[0]
+        assert len(ids) > 0
+        picks.append(rng.choice(ids, min(40, len(ids)), replace=False))
+    targets = rng.permutation(np.concatenate(picks)).astype(np.int64)
+    wo, no = o.prepare("gls", "u")
+    for _ in range(3):        # repeated calls reuse / reallocate the list buffer
+        w, nw = I.prepare_interpolator("gls", "u", targets)
+        assert util.rowscaled_err(w, wo[targets]) <= util.WEIGHT_RTOL
+        assert util.rowscaled_err(nw, no[targets]) <= util.WEIGHT_RTOL
+
+
 def test_gpu_2d_idw_ls(oracle_lib):
     """2-D quad + triangle mesh (z = 0): IDW uses grid.dim coordinates (idw.pyx:66), LS always three."""
     mesh = M.quad_tri_mesh_2d(12, 9, jitter=0.1, seed=1)
@@ -163,19 +190,81 @@ def test_gpu_gls_oversize_node_is_an_error_not_a_crash():
     assert W.shape == (I.grid.n_points, I.grid.n_elems)
 
 
-def test_gpu_apply_matches_matrix_product():
-    """Interpolator.apply == interpolate().dot(u) (the reference callers' next step, analytical.py:236)."""
+def test_gpu_apply_matches_oracle_matrix_product(oracle_lib):
+    """Interpolator.apply against the ORACLE's W . u (the reference callers' next step, analytical.py:236): one field
+    and a batch of three through nin_apply_fields_host, which computes the weights once."""
     mesh = M.mixed_mesh(10, 6, 6, jitter=0.1, seed=2)
     M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=4)
     I = _interp()
     I.load_mesh(mesh_obj=mesh)
+    o = oracle_lib.OracleInterpolator("port", threads=2)
+    o.load_mesh(mesh)
     u = np.concatenate(mesh.cell_data["u"])
+    rng = np.random.default_rng(0)
+    fields = np.stack([u, np.sin(3.0 * u), rng.uniform(-1.0, 1.0, len(u))])
     for meth in ("idw", "ls", "gls"):
-        W, nws = I.interpolate("u", meth)
-        vals, nws2 = I.apply("u", meth)
-        ref = W.dot(u)
-        np.testing.assert_array_equal(nws, nws2)
-        assert np.abs(vals - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), meth
+        Wo, nwo = o.interpolate("u", meth)
+        vals, nws = I.apply("u", meth)
+        assert vals.shape == (I.grid.n_points,)
+        ref = Wo.dot(u)
+        assert util.rowscaled_err(nws, nwo) <= util.WEIGHT_RTOL
+        assert np.abs(vals - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), meth
+        many, nws3 = I.apply("u", meth, values=fields)
+        assert many.shape == (3, I.grid.n_points)
+        np.testing.assert_array_equal(nws3, nws)
+        for k in range(3):
+            ref = Wo.dot(fields[k])
+            assert np.abs(many[k] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (meth, k)
+        np.testing.assert_array_equal(many[0], vals)      # a batch of k and k single calls are the same sums
+    with pytest.raises(ValueError):
+        I.apply("u", "gls", values=np.zeros((2, 5)))
+
+
+def _gls_degenerate_nodes(g, flag):
+    """The nodes outside GLS's parity set, from the grid arrays alone (gls.pyx:165-182,266-267): computed (not a
+    Dirichlet boundary node) but with no internal face at all (n_bface >= n_face: the reference leaves Mi empty) or
+    with fewer rows than unknowns next to the node value (m < n - 1: rank-deficient by count)."""
+    P = g.n_points
+    ep, fp = np.asarray(g.esup_ptr), np.asarray(g.fsup_ptr)
+    bf = np.asarray(g.boundary_faces).astype(bool)
+    bp = np.asarray(g.boundary_points).astype(bool)
+    neu = np.asarray(flag).astype(np.int64) != 0
+    fs = np.asarray(g.fsup)
+    nb_face = np.add.reduceat(np.append(bf[fs], False).astype(np.int64), fp[:-1])[:P] * (np.diff(fp) > 0)
+    ne, nf = np.diff(ep), np.diff(fp)
+    n_if = nf - nb_face
+    m = ne + 3 * n_if + np.where(neu, nb_face, 0)
+    n = 3 * ne + 1
+    computed = ~(bp & ~neu)
+    return computed, computed & ((n_if == 0) | (m < n - 1))
+
+
+@pytest.mark.parametrize("kind", ["hex", "tet", "mixed"])
+def test_gpu_gls_degenerate_set(oracle_lib, kind):
+    """The zero-row policy of the GLS kernels is applied on EXACTLY the nodes enumerated by _gls_degenerate_nodes -- on
+    a Neumann plane those are the box corners (one cell, no internal face) and, on tetrahedra, thin edge nodes -- and
+    nowhere else; every other computed node is non-empty and matches the oracle (DESIGN.md 'parity set')."""
+    mesh = {"hex": lambda: M.hex_mesh(5, 4, 4, jitter=0.1, seed=3), "tet": lambda: M.tet_mesh(4, jitter=0.1, seed=3),
+            "mixed": lambda: M.mixed_mesh(8, 4, 4, jitter=0.1, seed=3)}[kind]()
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=5)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    o = oracle_lib.OracleInterpolator("port", threads=2)
+    o.load_mesh(mesh)
+    flag = mesh.point_data["neumann_flag_u"]
+    computed, degenerate = _gls_degenerate_nodes(I.grid, flag)
+    if kind == "hex":      # (a Kuhn-split corner has several tetrahedra, hence internal faces: nothing degenerate there)
+        assert degenerate.sum() == 4, "the four corners of the Neumann plane: one cell, no internal face"
+    full = np.arange(I.grid.n_points)
+    w, nw = I.prepare_interpolator("gls", "u", full)
+    wo, no = o.prepare("gls", "u", full)
+    nonzero = np.abs(w).max(axis=1) > 0
+    assert not nonzero[degenerate].any(), "zero row on every degenerate node"
+    assert not nonzero[~computed].any(), "Dirichlet boundary nodes are skipped"
+    regular = computed & ~degenerate
+    assert nonzero[regular].all(), "every other computed node has weights"
+    assert util.rowscaled_err(w[regular], wo[regular]) <= util.WEIGHT_RTOL
+    assert util.rowscaled_err(nw[regular], no[regular]) <= util.WEIGHT_RTOL
 
 
 def test_gpu_integration_md_plugin_stub_runs_verbatim():

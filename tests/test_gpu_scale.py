@@ -94,3 +94,37 @@ def test_10m_hex_gls_properties():
     assert I.grid.n_elems == 10_077_696 and I.grid.n_points == 10_218_313
     W = _check_properties(I, mesh, "gls", linear_exact=False, tol_sum=1e-10)   # ALH tensor: heterogeneous K
     assert W.nnz == 8 * 215 ** 3
+
+
+def test_10m_mixed_gls_at_size(oracle_lib):
+    """configs[3] AT SIZE: GLS on the 10,094,400-cell hex | pyramid | tet mesh (200 x 120 x 120 lattice cells, node
+    degree 8 .. 26).  Closed-form counts, the size-independent properties, and the oracle itself on 4,096 nodes: eight
+    runs of 512 consecutive nodes (x-fastest numbering: each run crosses the hexahedron, transition and tetrahedron
+    regions), each with the cells around it cut out of the big mesh (partition.extract_submesh: every cell and face of
+    a sampled node is present, so its row is the row of the whole mesh) and mapped back to global column ids."""
+    import ninpol_amd
+    from ninpol_amd.partition import extract_submesh
+    mesh = M.mixed_mesh(200, 120, 120, jitter=0.1, seed=4)
+    M.attach_fields(mesh, "u", perm="ALH")
+    I = ninpol_amd.Interpolator(grid_build="device")
+    I.load_mesh(mesh_obj=mesh)
+    assert I.grid.n_elems == 10_094_400 and I.grid.n_points == 201 * 121 * 121 + 120 * 120   # + the pyramid apexes
+    W = _check_properties(I, mesh, "gls", linear_exact=False, tol_sum=1e-10)
+    ne = np.diff(np.asarray(I.grid.esup_ptr))
+    assert ne.max() == 26 and set(np.unique(ne[_interior(mesh)])) >= {8, 16, 24, 26}
+    rng = np.random.default_rng(7)
+    P = I.grid.n_points
+    worst, n_checked = 0.0, 0
+    for lo in rng.choice(P - 512, 8, replace=False):
+        lo = int(lo)
+        sub, pid, cid, owned = extract_submesh(mesh, lo, lo + 512)
+        o = oracle_lib.OracleInterpolator("port", threads=16)
+        o.load_mesh(sub)
+        Wo, _ = o.interpolate("u", "gls")
+        Wo = Wo.tocsr()[owned]
+        Wg = W[lo:lo + 512]
+        np.testing.assert_array_equal(np.diff(Wg.indptr), np.diff(Wo.indptr))
+        np.testing.assert_array_equal(Wg.indices, cid[Wo.indices])
+        worst = max(worst, util.csr_rowscaled_err(Wg, Wg.indptr, Wg.indices, Wo.data))
+        n_checked += 512
+    assert n_checked == 4096 and worst <= util.WEIGHT_RTOL, worst
