@@ -118,7 +118,10 @@ int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_m
  * `data[j] = weights + neumann_ws[row]` of interpolator.pyx:618 in the same kernel.
  * dev_csr_data [nnz_esup] and dev_neumann_ws [n_points] are DEVICE pointers; with targets == NULL the
  * launch is asynchronous on `stream`; with a target list the call returns once the kernels have run
- * (the device copy of the list is owned by the call). */
+ * (the device copy of the list is owned by the call).
+ * Threading: as in the reference, one Interpolator / grid is not re-entrant (interpolator.pxd: load_mesh mutates
+ * self.grid): the GLS launches of a grid share its work counters, so keep ONE nin_weights_* / nin_apply_* call in
+ * flight per grid (any number of grids may run concurrently, on the same or on different streams and devices). */
 int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t n_targets,
                        int add_neumann, double *dev_csr_data, double *dev_neumann_ws, void *stream);
 
@@ -153,6 +156,17 @@ int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t
                      double *dev_neumann_ws, void *stream);
 int nin_apply_fields_host(nin_grid *g, int method, const double *u_cells, int32_t n_fields, double *node_values,
                           double *neumann_ws);
+
+/* ---- native table packing (replaces the Python loops of interpolator.pyx:255-451, 501-509) ---------------------
+ * nin_pack_connectivity: interpolator.pyx:333-361 -- per-type cell blocks (block b: rows[b] x cols[b] int64 node ids,
+ *   element type type_id[b]) -> fixed-width, -1 padded connectivity [n_elems][8] + element_types [n_elems].
+ * nin_pack_table_row: interpolator.pyx:397-419 -- the first `take` columns of a row-major (n, src_cols) float64 array,
+ *   flattened into one row of a (n_vars, n * max_shape) data table.
+ * nin_diff_mag: interpolator.pyx:501-509 as compiled (`** (1 / 3)` is `** 0` under cdivision): (1 - 3 / tr K)^2. */
+int nin_pack_connectivity(int32_t n_blocks, const int64_t *const *block_data, const int64_t *rows, const int64_t *cols,
+                          const int64_t *type_id, int64_t *connectivity, int64_t *element_types);
+int nin_pack_table_row(const double *src, int64_t n, int64_t src_cols, int64_t take, double *dst);
+int nin_diff_mag(const double *permeability, int64_t n_elems, double *diff_mag);
 
 /* Algorithmic HBM bytes one nin_weights call moves for `method` over all nodes (DESIGN.md formula,
  * SURVEY 8d): used by bench.py for the roofline line. */

@@ -18,7 +18,7 @@ EXPORTS = (
     "nin_last_error", "nin_version", "nin_grid_create", "nin_grid_create_on_device", "nin_grid_destroy", "nin_grid_scalar",
     "nin_grid_array_info", "nin_grid_array_copy", "nin_device_count", "nin_grid_to_device", "nin_grid_device",
     "nin_fields_set", "nin_weights_device", "nin_weights_host", "nin_csr_compact_host", "nin_interpolate_csr_host", "nin_apply_host",
-    "nin_apply_device", "nin_apply_fields_host",
+    "nin_apply_device", "nin_apply_fields_host", "nin_pack_connectivity", "nin_pack_table_row", "nin_diff_mag",
     "nin_algorithmic_bytes", "nin_kernel_name",
 )
 
@@ -62,6 +62,9 @@ def load():
     L.nin_apply_host.argtypes = [vp, i32, vp, vp, vp]
     L.nin_apply_device.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     L.nin_apply_fields_host.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.nin_pack_connectivity.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    L.nin_pack_table_row.argtypes = [vp, i64, i64, i64, vp]
+    L.nin_diff_mag.argtypes = [vp, i64, vp]
     L.nin_algorithmic_bytes.argtypes = [vp, i32]
     L.nin_algorithmic_bytes.restype = i64
     L.nin_kernel_name.argtypes = [i32]

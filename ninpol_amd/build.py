@@ -19,6 +19,8 @@ ARCH = "gfx950"
 UNITS = [
     # host connectivity: g++ + libgomp; no FMA contraction (float32 normals must match the reference)
     ("grid_host.cpp", "g++", ["-fopenmp", "-ffp-contract=off"]),
+    # native table packing; diff_mag must be the reference's value bit for bit: no contraction either
+    ("pack_host.cpp", "g++", ["-fopenmp", "-ffp-contract=off"]),
     # IDW / LS: contraction off so results are the reference's bit for bit
     ("kernels_idw_ls.hip", "hipcc", ["-ffp-contract=off"]),
     ("kernels_gls.hip", "hipcc", []),

@@ -806,7 +806,13 @@ int launch_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t
                  double *out, double *nws, int32_t *queue, hipStream_t stream) {
     auto kern = nin_gls_block_kernel<NW, CS>;
     static const int dbg = getenv("NIN_GLS_BLOCK_DEBUG") ? atoi(getenv("NIN_GLS_BLOCK_DEBUG")) : 0;
-    static int lds_allowed = 48 * 1024;   // per instantiation: raise the dynamic-LDS limit once per new maximum
+    // per instantiation AND per device (the attribute belongs to the (function, device) pair and one process may
+    // drive several GPUs): raise the dynamic-LDS limit once per new maximum
+    static int lds_allowed_dev[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    int &lds_allowed = lds_allowed_dev[dev_id & 63];
+    if (lds_allowed == 0) lds_allowed = 48 * 1024;
     if (lds_bytes > lds_allowed) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return -3;

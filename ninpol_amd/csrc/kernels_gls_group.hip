@@ -587,8 +587,13 @@ int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int 
     if (blocks > 8) blocks &= ~(int64_t)7;
     static const int max_blocks = getenv("NIN_GLS_MAX_BLOCKS") ? atoi(getenv("NIN_GLS_MAX_BLOCKS")) : 0;
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-    static bool attr_set = false;
-    if (!attr_set) {   // 145 KB of dynamic LDS per block: above the default 64 KB limit
+    // 145 KB of dynamic LDS per block: above the default 64 KB limit.  The attribute belongs to the (function, device)
+    // pair, and one process may drive several GPUs: remembered per device
+    static bool attr_set_dev[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool &attr_set = attr_set_dev[dev_id & 63];
+    if (!attr_set) {
         const void *ks[4] = {reinterpret_cast<const void *>(nin_gls_group_kernel<0>), reinterpret_cast<const void *>(nin_gls_group_kernel<1>),
                              reinterpret_cast<const void *>(nin_gls_group_kernel<2>), reinterpret_cast<const void *>(nin_gls_group_kernel<3>)};
         for (const void *k : ks)

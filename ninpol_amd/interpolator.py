@@ -59,26 +59,39 @@ class _MethodPlugin:
     __call__ = prepare
 
 
-def _upload_fields(grid, method, cells_data, points_data, variable_to_index, variable):
+def _table_key(a):
+    """Identity of a resident field table: address, size and a hash of ALL its bytes (xxh3, ~10 GB/s: 70 ms for the
+    0.7 GB permeability table of a 10 M-cell mesh) -- a strided sample would miss an in-place edit between samples
+    and leave a stale K on the device.  Without xxhash: zlib.crc32 over the whole table."""
+    try:
+        import xxhash
+        h = xxhash.xxh3_64_intdigest(memoryview(a).cast("B"))
+    except ImportError:   # pragma: no cover
+        import zlib
+        h = zlib.crc32(memoryview(a).cast("B"))
+    return (a.__array_interface__["data"][0], a.size, h)
+
+
+def _upload_fields(grid, method, cells_data, points_data, variable_to_index, variable, device=0, always_perm=False):
     """Look the field rows up exactly as the plugins do (idw.pyx:27, ls.pyx:27, gls.pyx:47-59; a missing
-    name is a KeyError there too) and hand them to the device."""
+    name is a KeyError there too) and hand them to the device.  always_perm: upload permeability / diff_mag whenever
+    the mesh has them (a DevicePlan serves any method afterwards)."""
     L = _lib.load()
-    if grid.device < 0:
-        grid.to_device(0)
+    if grid.device < 0:   # the GPU its Interpolator was built for (a bare Grid handed to a plugin: device 0)
+        grid.to_device(getattr(grid, "preferred_device", device))
     P, E = grid.n_points, grid.n_elems
     v2i = variable_to_index
     flag = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_flag_" + variable]][:P], dtype=DTYPE_F)
     perm = dmag = nval = None
     key = None
-    if method == "gls":
+    if method == "gls" or (always_perm and "permeability" in v2i["cells"]):
         cd = np.asarray(cells_data)
         perm = np.ascontiguousarray(cd[v2i["cells"]["permeability"]][:E * 9], dtype=DTYPE_F)
         dmag = np.ascontiguousarray(cd[v2i["cells"]["diff_mag"]][:E], dtype=DTYPE_F)
-        nval = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_" + variable]][:P], dtype=DTYPE_F)
-        # permeability and diff_mag belong to the mesh: 0.8 GB at 10 M cells, uploaded once.  The key is the
-        # buffer's address and size plus a strided sample of its values, so a rebuilt or edited table goes up again.
-        step = max(1, perm.size // 8192)
-        key = (perm.__array_interface__["data"][0], perm.size, perm[::step].tobytes(), dmag[::max(1, dmag.size // 8192)].tobytes())
+        if method == "gls":
+            nval = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_" + variable]][:P], dtype=DTYPE_F)
+        # permeability and diff_mag belong to the mesh: 0.8 GB at 10 M cells, uploaded once per table contents
+        key = (_table_key(perm), _table_key(dmag))
         if getattr(grid, "_perm_key", None) == key and grid.device >= 0:
             perm = dmag = None
     _lib.check(L.nin_fields_set(grid._h, _ptr(perm), _ptr(dmag), _ptr(flag), _ptr(nval)))
@@ -158,6 +171,7 @@ class Interpolator:
         self.points_coords = np.ascontiguousarray(np.asarray(self.mesh_obj.points).astype(DTYPE_F))
         self.grid = Grid(*args, coords=self.points_coords, num_threads=self.num_threads,
                          build_device=self.device if self.grid_build == "device" else None)
+        self.grid.preferred_device = self.device
         self._log(f"Grid built in {time.time() - t0:.2f} seconds")
         t0 = time.time()
         self.variable_to_index = {"points": {}, "cells": {}, "faces": {}}
@@ -199,14 +213,17 @@ class Interpolator:
         blocks = [b for b in mesh.cells if b.type in self.types_per_dimension[dim]]
         n_elems = int(sum(len(b.data) for b in blocks))
         n_points = int(np.asarray(mesh.points).shape[0])
-        connectivity = -np.ones((max(n_elems, 0), T.MAX_POINTS_PER_ELEMENT), dtype=DTYPE_I)
-        element_types = -np.ones(max(n_elems, 0), dtype=DTYPE_I)
-        at = 0
-        for b in blocks:
-            d = np.asarray(b.data)
-            connectivity[at:at + len(d), :d.shape[1]] = d
-            element_types[at:at + len(d)] = T.ELEMENTS[b.type]["element_type"]
-            at += len(d)
+        connectivity = np.empty((max(n_elems, 0), T.MAX_POINTS_PER_ELEMENT), dtype=DTYPE_I)
+        element_types = np.empty(max(n_elems, 0), dtype=DTYPE_I)
+        # native packing (csrc/pack_host.cpp): -1 padded rows + types, block after block
+        data = [np.ascontiguousarray(np.asarray(b.data), dtype=DTYPE_I).reshape(len(b.data), -1) for b in blocks]
+        nb = len(blocks)
+        ptrs = (ctypes.c_void_p * max(nb, 1))(*[d.ctypes.data for d in data])
+        rows = np.array([d.shape[0] for d in data], dtype=DTYPE_I)
+        cols = np.array([d.shape[1] for d in data], dtype=DTYPE_I)
+        tids = np.array([T.ELEMENTS[b.type]["element_type"] for b in blocks], dtype=DTYPE_I)
+        _lib.check(_lib.load().nin_pack_connectivity(nb, ptrs, _ptr(rows), _ptr(cols), _ptr(tids), _ptr(connectivity),
+                                                     _ptr(element_types)))
         return (dim, n_elems, n_points, npoel, nfael, lnofa, lpofa, nedel, lpoed, connectivity, element_types,
                 self.logging, self.build_edges)
 
@@ -227,13 +244,12 @@ class Interpolator:
             self._log(f"Loading {data_type} data for variable '{variable}'")
             index = self.variable_to_index[data_type][variable]
             cur = int(dims[index])
-            a = np.asarray(data_dict[variable], dtype=DTYPE_F)
+            a = np.ascontiguousarray(data_dict[variable], dtype=DTYPE_F)
             if len(a) < n:
                 raise IndexError(f"index {len(a)} is out of bounds for axis 0 with size {len(a)}")
-            if cur == 1:
-                table[index, :n] = a[:n] if a.ndim == 1 else a[:n, 0]
-            else:
-                table[index, :n * cur] = a[:n].reshape(n, -1)[:, :cur].reshape(-1)
+            a2 = a.reshape(len(a), -1)     # row-major (len, src_cols); the native packer takes the first `cur` columns
+            if n:
+                _lib.check(_lib.load().nin_pack_table_row(_ptr(a2), n, a2.shape[1], cur, _ptr(table[index])))
         if data_type == "cells":
             self.cells_data_dimensions, self.cells_data = dims, table
         else:
@@ -259,11 +275,13 @@ class Interpolator:
         module is built with cdivision=True (setup.py:100-108), so the exponent is 0 and the value the
         reference uses is (1 - 3 / tr K)^2.  Only this form reproduces the GLS numbers the reference
         publishes (tests/test_kat.py)."""
-        K = np.reshape(np.asarray(permeability, dtype=DTYPE_F), (len(permeability), 9))
-        tr = (K[:, 0] + K[:, 4]) + K[:, 8]           # np.trace's order
+        K = np.ascontiguousarray(np.reshape(np.asarray(permeability, dtype=DTYPE_F), (len(permeability), 9)))
         # det ** 0 == 1.0 for every float (0, inf and nan included), so the determinant is not computed:
-        # 3 * 1.0 / tr is the value the reference's expression yields, bit for bit
-        return (1 - (3 * 1.0 / tr)) ** 2
+        # (1 - 3 * 1.0 / tr)^2, tr in np.trace's order, is the value the reference's expression yields, bit for bit
+        # (native: csrc/pack_host.cpp, built without FMA contraction)
+        out = np.empty(len(K), dtype=DTYPE_F)
+        _lib.check(_lib.load().nin_diff_mag(_ptr(K), len(K), _ptr(out)))
+        return out
 
     def load_face_data(self, data_dict, face_connectivity=np.array([[]], dtype=int)):
         """interpolator.pyx:456-499."""
@@ -417,18 +435,9 @@ class DevicePlan:
         self.method = method
         self.method_id = _lib.METHOD_ID[method]
         L = _lib.load()
-        if g.device < 0:
-            g.to_device(interp.device)
-        P, E = g.n_points, g.n_elems
-        v2i = interp.variable_to_index
-        flag = np.ascontiguousarray(np.asarray(interp.points_data)[v2i["points"]["neumann_flag_" + variable]][:P],
-                                    dtype=DTYPE_F)
-        perm = dmag = None
-        if "permeability" in v2i["cells"]:
-            cd = np.asarray(interp.cells_data)
-            perm = np.ascontiguousarray(cd[v2i["cells"]["permeability"]][:E * 9], dtype=DTYPE_F)
-            dmag = np.ascontiguousarray(cd[v2i["cells"]["diff_mag"]][:E], dtype=DTYPE_F)
-        _lib.check(L.nin_fields_set(g._h, _ptr(perm), _ptr(dmag), _ptr(flag), None))
+        _upload_fields(g, method, interp.cells_data, interp.points_data, interp.variable_to_index, variable,
+                       device=interp.device, always_perm=True)
+        P = g.n_points
         self.nnz = int(L.nin_grid_scalar(g._h, b"nnz_esup"))
         self.n_points = P
         self.algorithmic_bytes = int(L.nin_algorithmic_bytes(g._h, self.method_id))

@@ -206,3 +206,36 @@ def test_load_arrays_equals_load_mesh():
     assert np.array_equal(a.cells_data, b.cells_data) and np.array_equal(a.points_data, b.points_data)
     for k in ("esup", "esup_ptr", "fsup", "inpofa", "centroids", "normal_faces"):
         assert np.array_equal(getattr(a.grid, k), getattr(b.grid, k)), k
+
+
+def test_native_table_packing_matches_numpy(lib):
+    """process_mesh / load_data / diff_mag run in the native library (csrc/pack_host.cpp); the tables must
+    be what the vectorised numpy formulation (and, through the golden fixtures, the reference) gives, bit for bit."""
+    import ninpol_amd
+    from ninpol_amd import topology as T
+    mesh = M.mixed_mesh(7, 4, 4, jitter=0.1, seed=2)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=1)
+    I = ninpol_amd.Interpolator()
+    args = I.process_mesh(mesh)
+    conn, etypes = args[9], args[10]
+    n_elems = sum(len(b.data) for b in mesh.cells)
+    ref_c = -np.ones((n_elems, 8), dtype=np.int64)
+    ref_t = -np.ones(n_elems, dtype=np.int64)
+    at = 0
+    for b in mesh.cells:
+        d = np.asarray(b.data)
+        ref_c[at:at + len(d), :d.shape[1]] = d
+        ref_t[at:at + len(d)] = T.ELEMENTS[b.type]["element_type"]
+        at += len(d)
+    np.testing.assert_array_equal(conn, ref_c)
+    np.testing.assert_array_equal(etypes, ref_t)
+    K = np.concatenate(mesh.cell_data["permeability"]).reshape(-1, 9)
+    tr = (K[:, 0] + K[:, 4]) + K[:, 8]
+    np.testing.assert_array_equal(I.compute_diffusion_magnitude(K), (1 - (3 * 1.0 / tr)) ** 2)
+    I.load_mesh(mesh_obj=mesh)
+    v2i = I.variable_to_index
+    assert list(v2i["cells"]) == ["permeability", "diff_mag", "u"]          # dict-insertion order of the reference
+    E = I.grid.n_elems
+    np.testing.assert_array_equal(np.asarray(I.cells_data)[v2i["cells"]["permeability"]][:E * 9], K.reshape(-1))
+    np.testing.assert_array_equal(np.asarray(I.cells_data)[v2i["cells"]["u"]][:E], np.concatenate(mesh.cell_data["u"]))
+    np.testing.assert_array_equal(np.asarray(I.points_data)[v2i["points"]["neumann_u"]], mesh.point_data["neumann_u"])
