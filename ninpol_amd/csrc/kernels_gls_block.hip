@@ -102,6 +102,8 @@ struct Sys {       // one node's system, wave-uniform
     double *A;     // [n + 1][ld] column-major, ld odd >= m; column n stays zero (parking column for dead lanes)
     double *aux;   // partial dots [2][NW][n]; later y[n] and the weight row
     int n, m, ld, lane, wave;
+    int pstride;   // entries per wave in a partial-dot buffer: n, or -- packed -- the live columns of the dense phase
+    bool db;       // partial dots double-buffered: one workgroup barrier per step instead of two
     double *stamps;
 };
 
@@ -128,7 +130,7 @@ __device__ __forceinline__ void first_dots(const Sys &s, int k0, double (&dn)[CS
 }
 
 // Householder step k.  TOP = slot of the pivot column (the highest slot with a live column).
-template <int NW, int CS, int TOP, bool DB>
+template <int NW, int CS, int TOP>
 __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&dn)[CS], double (&rkeep)[CS],
                                         bool &singular) {
     const int n = s.n, m = s.m, lane = s.lane;
@@ -146,10 +148,11 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
         if (NW == 1) {
             d[q] = dn[q];
         } else {
-            const double *P = s.aux + ((DB ? buf : 0) * NW * n + (jj < n ? jj : n - 1));   // dead lanes: any valid word
+            const int ps = s.pstride;
+            const double *P = s.aux + ((s.db ? buf : 0) * NW * ps + (jj < ps ? jj : ps - 1));   // dead lanes: any valid word
             double part[NW];
 #pragma unroll
-            for (int u = 0; u < NW; ++u) part[u] = P[u * n];
+            for (int u = 0; u < NW; ++u) part[u] = P[u * ps];
             double acc = part[0];
 #pragma unroll
             for (int u = 1; u < NW; ++u) acc += part[u];
@@ -159,7 +162,7 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
         rowk[q] = col[q][k];          // dead lanes read the parking column: 0
         dn[q] = 0.0;
     }
-    if (NW > 1 && !DB) group_sync<NW>();   // one partial buffer: nobody may publish before everybody has read
+    if (NW > 1 && !s.db) group_sync<NW>();   // one partial buffer: nobody may publish before everybody has read
     NIN_STAMP(s, k, 0);
     const double dk = readlane_f64(d[TOP], lk), alpha = readlane_f64(rowk[TOP], lk);
     if (!(dk != 0.0)) singular = true;                  // an all-zero pivot column (or NaN): no solution row
@@ -250,7 +253,7 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
     }
     NIN_STAMP(s, k, 2);
     if (NW > 1) {
-        double *P = s.aux + ((size_t)(DB ? (buf ^ 1) : 0) * NW + s.wave) * n;
+        double *P = s.aux + ((size_t)(s.db ? (buf ^ 1) : 0) * NW + s.wave) * s.pstride;
 #pragma unroll
         for (int q = 0; q <= TOP; ++q)
             if (upd[q]) P[lane + 64 * q] = dn[q];
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
         s.A = sys_lds;
         s.aux = sys_lds + (size_t)(n + 1) * ld;
         s.n = n; s.m = m; s.ld = ld; s.lane = lane; s.wave = wave;
+        s.pstride = n; s.db = DB;
 #ifdef NIN_BLOCK_STAMPS
         s.stamps = (dbg >> 8) == p ? nws : nullptr;   // NIN_GLS_BLOCK_DEBUG = node << 8: that node's block records
 #else
@@ -685,6 +689,10 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             for (int rk = wave; rk < n1; rk += NW)
                 if (front_qr<CS>(s, rk, pl.lst[rk], pl.nl[rk])) *sing = 1;
             group_sync<NW>();
+            // the dense phase only ever publishes the live columns (reversed indices 0 .. n - 1 - R0): packed to that
+            // length, two buffers may fit where one of length n did -- one barrier per step instead of two
+            const int nlive = n - R0;
+            if (!DB && 2 * NW * nlive <= AUXW * n) { s.db = true; s.pstride = nlive; }
         }
 
         // ---- Householder QR of the remaining columns R0 .. n-2, the last one carried along ---------------------------
@@ -700,10 +708,10 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
         }
         int buf = 0;
         if (NW > 1) {
-            double *P = s.aux + (size_t)wave * n;
+            double *P = s.aux + (size_t)wave * s.pstride;
 #pragma unroll
             for (int q = 0; q < CS; ++q)
-                if (lane + 64 * q < n) P[lane + 64 * q] = dn[q];
+                if (lane + 64 * q < s.pstride) P[lane + 64 * q] = dn[q];
             group_sync<NW>();
         }
         for (int k = R0; k < n - 1; ++k) {
@@ -715,12 +723,12 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                 }
             }
             const int top = (n - 1 - k) >> 6;
-#define NIN_TOP(T) if (CS > T && top == T) qr_step<NW, CS, T, DB>(s, k, buf, dn, rkeep, singular)
+#define NIN_TOP(T) if (CS > T && top == T) qr_step<NW, CS, T>(s, k, buf, dn, rkeep, singular)
             NIN_TOP(0); NIN_TOP(1); NIN_TOP(2); NIN_TOP(3);
 #undef NIN_TOP
             if (NW > 1) {
                 group_sync<NW>();
-                if (DB) buf ^= 1;
+                if (s.db) buf ^= 1;
             }
             NIN_STAMP(s, k, 3);
         }
@@ -749,12 +757,12 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                 }
             };
             load_col(n - 2, coln);
-            for (int k = n - 2; k >= 0; --k) {
+            for (int k = n - 2; k >= R0; --k) {
                 const int ks = k >> 6, kl = k & 63;
                 double col[CS];
 #pragma unroll
                 for (int q = 0; q < CS; ++q) col[q] = coln[q];
-                if (k > 0) load_col(k - 1, coln);
+                if (k > R0) load_col(k - 1, coln);
                 double rkk = 1.0, ck = 0.0;
 #pragma unroll
                 for (int q = 0; q < CS; ++q) {
@@ -767,6 +775,25 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
 #pragma unroll
                 for (int q = 0; q < CS; ++q) ct[q] = fma(-yk, col[q], ct[q]);
                 if (lane == 0) y[k] = yk;
+            }
+            if (SPARSE && R0 > 0) {
+                // the columns of the phase-1 fronts: R couples a front's three rows only to each other (and to the
+                // columns >= R0, already taken off the right-hand side above) -- all fronts at once, a lane each
+                double *ctl = s.aux + 2 * n;       // (AUXW >= 4 for NW > 1: room behind y and the weight row)
+#pragma unroll
+                for (int q = 0; q < CS; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < R0) ctl[i] = ct[q];
+                }
+                group_sync<1>();
+                if (3 * lane < R0) {
+                    const int r0 = 3 * lane;
+                    const double *A0 = s.A + (size_t)r0 * ld, *A1 = A0 + ld, *A2 = A1 + ld;   // columns r0, r0 + 1, r0 + 2
+                    const double y2 = ctl[r0 + 2] * fast_rcp(A2[r0 + 2]);
+                    const double y1 = fma(-A2[r0 + 1], y2, ctl[r0 + 1]) * fast_rcp(A1[r0 + 1]);
+                    const double y0 = fma(-A2[r0], y2, fma(-A1[r0], y1, ctl[r0])) * fast_rcp(A0[r0]);
+                    y[r0] = y0; y[r0 + 1] = y1; y[r0 + 2] = y2;
+                }
             }
             double rr = 0.0;
             for (int i = n - 1 + lane; i < m; i += 64) {
