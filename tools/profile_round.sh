@@ -16,6 +16,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
   i=$((i+1))
   timeout -k 10 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-other-meshes > $OUT/pmc$i.json 2> $OUT/pmc$i.err || { echo "pmc pass $i failed"; tail -5 $OUT/pmc$i.err; exit 1; }
 done
+# the block kernel by size class on the mixed and Kuhn-tet meshes (BASELINE config [3] at size: mixed10m)
+NIN_GRID_BUILD=device timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mixed_tet -- python3 tools/time_methods.py mixed tet40 wedge60 mixed10m > $OUT/methods_by_mesh.txt 2> $OUT/mixed_tet.err || { echo "mixed/tet pass failed"; tail -5 $OUT/mixed_tet.err; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, json, collections, os
 out = sys.argv[1]
@@ -30,6 +32,10 @@ with open(out + "/kernel_stats.csv", "w", newline="") as f:
 tr = glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True)[0]
 with open(out + "/kernel_trace_head.csv", "w") as f:
     f.writelines(open(tr).readlines()[:40])
+mt = glob.glob(out + "/mixed_tet/**/*kernel_stats.csv", recursive=True)
+if mt:
+    with open(out + "/kernel_stats_mixed_tet.csv", "w", newline="") as f:
+        csv.writer(f, quoting=csv.QUOTE_ALL).writerows([r for r in csv.reader(open(mt[0]))])
 acc = collections.defaultdict(list)
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
