@@ -111,6 +111,33 @@ def test_gpu_target_subset_spans_gls_classes(oracle_lib):
         assert util.rowscaled_err(nw, no[targets]) <= util.WEIGHT_RTOL
 
 
+def test_gpu_interior_neumann_flags(oracle_lib):
+    """The Neumann flag on INTERIOR nodes (gls.pyx:470-472, interpolator.pyx:618): neumann_ws = the last cell's weight,
+    added to every stored entry of the row -- through the multifrontal kernel (cube nodes of the hexahedron region) and
+    the block kernel (tetrahedron / transition nodes) alike."""
+    mesh = M.mixed_mesh(10, 5, 5, jitter=0.1, seed=5)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=6)
+    rng = np.random.default_rng(3)
+    P = mesh.points.shape[0]
+    flagged = rng.choice(P, P // 3, replace=False)
+    mesh.point_data["neumann_flag_u"][flagged] = 1.0
+    mesh.point_data["neumann_u"][flagged] = rng.uniform(0.0, 1.0, len(flagged))
+    o = oracle_lib.OracleInterpolator("port", threads=4)
+    o.load_mesh(mesh)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    bp = np.asarray(I.grid.boundary_points).astype(bool)
+    assert (~bp[flagged]).sum() > 50
+    for meth in ("gls", "idw", "ls"):
+        W, nws = I.interpolate("u", meth)
+        Wo, nwo = o.interpolate("u", meth)
+        tol = util.WEIGHT_RTOL if meth == "gls" else 1e-14
+        assert util.csr_rowscaled_err(W, Wo.indptr, Wo.indices, Wo.data) <= tol, meth
+        assert util.rowscaled_err(nws, nwo) <= tol, meth
+        if meth == "gls":    # the interior flagged rows do carry a neumann_ws
+            assert np.abs(nws[flagged][~bp[flagged]]).min() > 0.0
+
+
 def test_gpu_2d_idw_ls(oracle_lib):
     """2-D quad + triangle mesh (z = 0): IDW uses grid.dim coordinates (idw.pyx:66), LS always three."""
     mesh = M.quad_tri_mesh_2d(12, 9, jitter=0.1, seed=1)
