@@ -183,7 +183,7 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
     // The sweep: rows i0, i0 + NW, ... of this wave, G at a time with the next G loads in flight.  Inside a
     // lane's column those rows are NW doubles apart: every access is base + immediate.  Dead lanes of the top
     // slot work on the parking column (0 in, w = 0, 0 out); with a single slot they are simply masked off.
-    constexpr int G = TOP == 0 ? 8 : 4;
+    constexpr int G = TOP == 0 ? 6 : 4;   // (6, not 8: the partial last group runs unpipelined -- fewer rows end up in it; A/B: -4 %)
     const int i0 = k + 1 + ((s.wave - (k + 1)) % NW + NW) % NW;
     const int rows = i0 < m ? (m - i0 + NW - 1) / NW : 0;
     const int full = rows / G, rem = rows % G;
