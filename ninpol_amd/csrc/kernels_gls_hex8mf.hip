@@ -327,7 +327,18 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
         cur.level2(g);
         cur.level3(g);
     }
+#ifdef NIN_MF_STAMPS
+    unsigned long long stamps[8];
+    int n_stamp = 0, pass_no = 0;
+#define NIN_MF_STAMP() do { if (n_stamp < 8) { __builtin_amdgcn_sched_barrier(0); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define NIN_MF_STAMP() do { } while (0)
+#endif
     while (wg < wg_end) {
+#ifdef NIN_MF_STAMPS
+        n_stamp = 0;
+#endif
+        NIN_MF_STAMP();                                   // 0: top of the pass
         const bool valid = cur.valid;
         const uint32_t p = cur.p, eb = cur.eb;
         const uint32_t dsc = cur.dsc;
@@ -368,6 +379,7 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
                 for (int t = 0; t < 3; ++t) { P[2 + 3 * i][t] = sav[i][0][t]; P[3 + 3 * i][t] = sav[i][1][t]; }
             }
         }
+        NIN_MF_STAMP();                                   // 1: face rows done
         // next pass: list entry, and the ticket of the pass after it.  Tied to the face rows above: the geometry this
         // pass has just consumed must have been waited for BEFORE these go out, or that wait covers them too
         nx.level0(nodes, desc, wg_next * NPW + nd, count, l, q, leader, (P[3][2] + P[6][2]) + P[9][2]);
@@ -482,18 +494,23 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
         C[7][12] = 1.0;
 
         // ---- phase 2: 32 x 12 over the quad ------------------------------------------------------------------
+        NIN_MF_STAMP();                                   // 2: phase 1 done
         nx.level1(g);   // next pass: CSR row starts, node coordinates, flags
         double rinvq[3] = {0.0, 0.0, 0.0};
         P2Loop<0, 6>::run(C, rinvq, l);
+        NIN_MF_STAMP();                                   // 3: phase 2, steps 0-5
         nx.level2(g);   // next pass: cell and face ids
         P2Loop<6, 12>::run(C, rinvq, l);
+        NIN_MF_STAMP();                                   // 4: phase 2 done
         // next pass: geometry and permeability.  Issued HERE: the registers phase 2 has just released take them, and
         // the back-substitution and the weights below (~2.5 k cycles, mostly dependent chains) cover their latency
         __builtin_amdgcn_sched_barrier(0);
         nx.level3(g);
         __builtin_amdgcn_sched_barrier(0);
         double y[12], t3[3] = {C[0][12], C[1][12], C[2][12]};
+        NIN_MF_STAMP();                                   // 5: geometry of the next pass requested
         BackLoop<11>::run(C, rinvq, t3, y, l);
+        NIN_MF_STAMP();                                   // 6: back-substitution done
         double tail = 0.0;
 #pragma unroll
         for (int r = 3; r < NR; ++r) tail = fma(C[r][12], C[r][12], tail);
@@ -530,6 +547,11 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
             if (l == 0) nws[p] = nwv;
         }
         wave_lds_sync();
+        NIN_MF_STAMP();                                   // 7: weights stored
+#ifdef NIN_MF_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0 && ++pass_no == 8)
+            for (int i = 0; i < 8; ++i) nws[nodes[i]] = (double)(stamps[i] - stamps[0]);   // (diagnostic build: clobbers neumann_ws of the first 8 listed nodes)
+#endif
         cur = nx;
         wg = wg_next;
         wg_next = wg_lo + (int32_t)__builtin_amdgcn_readfirstlane(nx.ticket);
