@@ -89,7 +89,8 @@ class ShardedPlan:
     """Device-resident `interpolate(variable, method)` over the process group: this rank's kernel writes its node
     block's CSR values, ONE all-gather per step reassembles the (count, column, value) triplets + the Neumann array on
     every rank.  Columns and counts do not depend on the step (they are the esup rows of the owned nodes, global cell
-    ids): they are gathered once, here; a step moves 8 B per entry + 8 B per row.
+    ids): they are gathered once, here; a step moves 8 B per entry (+ 8 B per row for the Neumann array, only when it
+    can be non-zero at all).
 
     Shards are padded to the longest (RCCL has no allgatherv); rank r's piece of a gathered tensor `t` is
     t[r * mx : r * mx + lens[r]].  Two output / gather buffer sets rotate: `step()` returns at once, the gather of step
@@ -129,7 +130,14 @@ class ShardedPlan:
         self.out = [torch.zeros(n_out, dtype=torch.float64, device=dev) for _ in range(2)]
         self.nws = [torch.zeros(n_nws, dtype=torch.float64, device=dev) for _ in range(2)]
         self.vals = [torch.empty(S.world * self.mx_nnz, dtype=torch.float64, device=dev) for _ in range(2)]
-        self.neumann = [torch.empty(S.world * self.mx_rows, dtype=torch.float64, device=dev) for _ in range(2)]
+        # neumann_ws is identically zero unless the method is GLS and some node of the mesh carries the Neumann flag
+        # (idw.pyx / ls.pyx never write it; gls.pyx:470-472 only on flagged nodes): decided once, over all ranks, and
+        # then not gathered at all -- 11 % of a step's bytes on an all-Dirichlet hexahedron mesh
+        flagged = torch.tensor([1 if (method == "gls" and S._any_neumann_flag(variable)) else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flagged, op=dist.ReduceOp.MAX, group=S.group)
+        self.gather_neumann = bool(int(flagged[0]))
+        self.neumann = [(torch.empty if self.gather_neumann else torch.zeros)(S.world * self.mx_rows, dtype=torch.float64, device=dev)
+                        for _ in range(2)]
         self.pending = [None, None]
         self.n_steps = 0
 
@@ -156,8 +164,9 @@ class ShardedPlan:
         if events is not None:
             events[1].record()
         lo = S.own_lo
-        self.pending[b] = [S._gather(self.vals[b], self.out[b][self.eb:self.eb + self.mx_nnz], async_op=True),
-                           S._gather(self.neumann[b], self.nws[b][lo:lo + self.mx_rows], async_op=True)]
+        self.pending[b] = [S._gather(self.vals[b], self.out[b][self.eb:self.eb + self.mx_nnz], async_op=True)]
+        if self.gather_neumann:
+            self.pending[b].append(S._gather(self.neumann[b], self.nws[b][lo:lo + self.mx_rows], async_op=True))
         self.pending[b] = [w for w in self.pending[b] if w is not None] or None
         return b
 
@@ -227,6 +236,15 @@ class ShardedInterpolator:
             self.local = self._make()
         self.local.load_mesh(mesh_obj=shard_mesh)
         self._plans = {}
+
+    def _any_neumann_flag(self, variable):
+        """Does any node of this rank's shard carry neumann_flag_<variable>?  (True when the compute object does not
+        expose its point table: then the Neumann array is always gathered.)"""
+        try:
+            row = self.local.variable_to_index["points"]["neumann_flag_" + variable]
+            return bool(np.any(np.asarray(self.local.points_data)[row].astype(np.int64) != 0))
+        except (AttributeError, KeyError, IndexError, TypeError):
+            return True
 
     def global_cells(self, local_ids):
         return local_ids + self.cell_ids if np.isscalar(self.cell_ids) else np.asarray(self.cell_ids)[local_ids]

@@ -31,6 +31,10 @@ SLAB = (5, 4, 9)   # the slab case: hex_mesh(5, 4, 9), node planes dealt to the 
 
 
 def _make_mesh(kind):
+    if kind == "hexfree":     # all-Dirichlet boundary: neumann_ws is identically zero and is not gathered at all
+        m = M.hex_mesh(5, 6, 6, jitter=0.15, seed=1)
+        M.attach_fields(m, "u", perm="ALH", seed=5)
+        return m
     if kind == "slab":
         m = M.hex_mesh(*SLAB, jitter=0.15, seed=1)
     elif kind == "mixed":
@@ -68,6 +72,7 @@ class _OracleCompute:
     def load_mesh(self, filename="", mesh_obj=None):
         self.o.load_mesh(mesh_obj)
         self.grid = self.o.grid
+        self.variable_to_index, self.points_data = self.o.variable_to_index, self.o.points_data   # (the Neumann flags)
 
     def device_plan(self, variable, method):
         return _OraclePlan(self.o, variable, method)
@@ -95,6 +100,7 @@ def _worker(rank, world, port, kind, out_dir):
             S.load_mesh(_make_mesh(kind))
         for meth in ("idw", "ls", "gls"):
             W, nws = S.interpolate("u", meth)
+            assert S.device_plan("u", meth).gather_neumann == (meth == "gls" and kind != "hexfree")
             W2, nws2 = S.interpolate("u", meth)    # second step: the other buffer set of the rotation
             assert np.array_equal(W.data, W2.data) and np.array_equal(nws, nws2, equal_nan=True)
             np.savez(os.path.join(out_dir, f"r{rank}_{meth}.npz"), indptr=W.indptr, indices=W.indices,
@@ -103,7 +109,7 @@ def _worker(rank, world, port, kind, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["hex", "mixed", "slab"])
+@pytest.mark.parametrize("kind", ["hex", "mixed", "slab", "hexfree"])
 def test_two_rank_gather_matches_single(tmp_path, oracle_lib, kind):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
