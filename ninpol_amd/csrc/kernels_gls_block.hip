@@ -119,7 +119,22 @@ __device__ __forceinline__ void first_dots(const Sys &s, int k0, double (&dn)[CS
     const double *col[TOP + 1];
 #pragma unroll
     for (int q = 0; q <= TOP; ++q) col[q] = lane_column(s, q, s.lane + 64 * q < s.n);
-    for (int i = k0 + ((s.wave - k0) % NW + NW) % NW; i < s.m; i += NW) {
+    // four rows at a time: their loads go out together (a row at a time this pass is a chain of LDS latencies)
+    int i = k0 + ((s.wave - k0) % NW + NW) % NW;
+    for (; i + 3 * NW < s.m; i += 4 * NW) {
+        double own[4][TOP + 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q <= TOP; ++q) own[u][q] = col[q][i + u * NW];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double x = readlane_f64(own[u][TOP], l0);
+#pragma unroll
+            for (int q = 0; q <= TOP; ++q) dn[q] = fma(x, own[u][q], dn[q]);
+        }
+    }
+    for (; i < s.m; i += NW) {
         double own[TOP + 1];
 #pragma unroll
         for (int q = 0; q <= TOP; ++q) own[q] = col[q][i];
@@ -183,7 +198,7 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
     // The sweep: rows i0, i0 + NW, ... of this wave, G at a time with the next G loads in flight.  Inside a
     // lane's column those rows are NW doubles apart: every access is base + immediate.  Dead lanes of the top
     // slot work on the parking column (0 in, w = 0, 0 out); with a single slot they are simply masked off.
-    constexpr int G = TOP == 0 ? 6 : 4;   // (6, not 8: the partial last group runs unpipelined -- fewer rows end up in it; A/B: -4 %)
+    constexpr int G = TOP == 0 ? 5 : 4;   // (5, not 8: the partial last group runs unpipelined -- fewer rows end up in it; A/B: -4 %)
     const int i0 = k + 1 + ((s.wave - (k + 1)) % NW + NW) % NW;
     const int rows = i0 < m ? (m - i0 + NW - 1) / NW : 0;
     const int full = rows / G, rem = rows % G;
