@@ -25,7 +25,6 @@ UNITS = [
     ("kernels_idw_ls.hip", "hipcc", ["-ffp-contract=off"]),
     ("kernels_gls.hip", "hipcc", []),
     ("kernels_gls_block.hip", "hipcc", []),
-    ("kernels_gls_group.hip", "hipcc", []),
     # no atomic optimizer: it turns the work-queue atomicAdd into mbcnt + readfirstlane of the returned value right
     # behind the atomic, i.e. a full round-trip wait at the top of every pass; left alone the value is first read at
     # the end of the pass (kernels_gls_hex8mf.hip, grab_issue / grab_value)

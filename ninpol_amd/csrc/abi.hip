@@ -432,12 +432,9 @@ int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_m
     return NIN_OK;
 }
 
-// cube nodes: the multifrontal kernel (NIN_GLS_HEX8_KERNEL=group: the dense 16-lanes-per-node kernel it replaced,
-// kept for A/B timing)
+// cube nodes: the multifrontal kernel
 static int launch_hex8(DeviceGrid &d, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
                        double *out, double *nws, hipStream_t stream) {
-    static const bool dense = getenv("NIN_GLS_HEX8_KERNEL") && std::string(getenv("NIN_GLS_HEX8_KERNEL")) == "group";
-    if (dense) return launch_gls_hex8(d.v, nodes, count, add_neumann, out, nws, d.gls_queue, stream);
     return launch_gls_hex8mf(d.v, nodes, desc, count, add_neumann, out, nws, d.gls_queue, stream);
 }
 

@@ -1,6 +1,6 @@
 // kernels_gls.hip -- GLS weights, gfx950: one node per wavefront, the system in a global-memory scratch slot.
 // This is the fallback for nodes whose system does not fit the LDS of one CU (more than ~85 cells around a
-// node); everything else runs in kernels_gls_block.hip (LDS) or kernels_gls_group.hip (registers).
+// node); everything else runs in kernels_gls_block.hip (LDS) or kernels_gls_hex8mf.hip (registers).
 //
 // What the reference does per node (gls.pyx:161-219): assemble the dense m x n system
 //   M = [ d_i^T on block i | 1 ]        n_elem rows    (x_K - x_v, gls.pyx:269-281)

@@ -21,7 +21,7 @@
 //            rows evenly; the scalar chain of a step (beta, 1 / (beta (beta - alpha))) overlaps the partial dots,
 //            which do not need it: v = x - beta e_p differs from x in the pivot lane's pivot entry only, a local fix;
 //   then     R y = Q^T c by columns over the quad, r_i = 1 - d_i . y_i per cell, r . r from the 20 rows left over,
-//            weights r_i / (r . r)  (the identity X[n-1, i] = r_i / (r.r), SURVEY 7.1(i), kernels_gls_group.hip).
+//            weights r_i / (r . r)  (the identity X[n-1, i] = r_i / (r.r), SURVEY 7.1(i), kernels_gls_block.hip).
 // ~6 k FP64 FMAs per node against ~20 k for the dense sweep, none of them masked out, and no LDS traffic inside
 // the factorisation (the dense kernel published every pivot column through LDS: 22 writes per step).
 // Same mathematics as dgels on the reference's matrix -- a Householder QR, only in a column order that exposes the
@@ -29,7 +29,7 @@
 //
 // Eligible nodes are binned at load time (k_classify + hex8_desc.hpp): 8 cells, 12 internal faces, cube graph.
 // Everything else runs in kernels_gls_block.hip.  The launch is persistent and XCD-aware (per-XCD work counters),
-// as the dense group kernel's was.
+// as the dense 16-lanes-per-node kernel of round 1 (41 ms, removed) was.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -23,13 +23,9 @@ int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int
 int launch_gls_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t waves, int32_t col_slots,
                      int32_t lds_bytes, int add_neumann, double *out, double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_block();
-// the register-resident group kernel for (8 cells, 12 internal faces) nodes, kernels_gls_group.hip
-// `queue`: kGlsQueueInts zeroed device ints (one work counter per XCD, each on its own cache line)
-int launch_gls_hex8(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out,
-                    double *nws, int32_t *queue, hipStream_t stream);
-const char *kernel_name_gls_hex8();
 // the multifrontal kernel for cube nodes (kernels_gls_hex8mf.hip): 4 lanes per node; `desc` = 4 descriptor words per
-// list entry (hex8_desc.hpp, filled by launch_hex8_desc); `queue` as above
+// list entry (hex8_desc.hpp, filled by launch_hex8_desc);
+// `queue`: kGlsQueueInts zeroed device ints (one work counter per XCD, each on its own cache line)
 int launch_hex8_desc(const GridView &g, const int32_t *nodes, int32_t count, int32_t *desc, hipStream_t stream);
 int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
                       double *out, double *nws, int32_t *queue, hipStream_t stream);
