@@ -15,6 +15,7 @@
 #include "device_grid.hpp"
 #include "grid_host.hpp"
 #include "launch.hpp"
+#include "mfw_desc.hpp"
 
 using namespace nin;
 
@@ -343,8 +344,9 @@ int nin_grid_to_device(nin_grid *g, int device) {
     // ---- GLS launch plan: bin nodes by the size of their least-squares system (classified on the device) ----
     g->node_class.assign((size_t)P, 0);
     std::vector<std::vector<int32_t>> lists(kGlsClasses);
-    std::vector<int32_t> hex8_list;
-    const bool use_group = getenv("NIN_GLS_NO_GROUP") == nullptr;   // debugging switch: force the generic kernel
+    std::vector<int32_t> hex8_list, mfw_list;
+    // debugging switches: keep nodes away from the hex8 kernel (bit 0) / the one-wavefront multifrontal kernel (bit 1)
+    const int use_group = (getenv("NIN_GLS_NO_GROUP") == nullptr ? 1 : 0) | (getenv("NIN_GLS_NO_MFW") == nullptr ? 2 : 0);
     const bool force_global = getenv("NIN_GLS_FORCE_GLOBAL") != nullptr;   // testing switch: systems in global scratch
     int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0}, cols_max[kGlsClasses] = {0};
     {
@@ -366,6 +368,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
     for (int64_t p = 0; p < P; ++p) {
         const uint8_t c = g->node_class[p];
         if (c == 255) hex8_list.push_back((int32_t)p);
+        else if (c == 254) mfw_list.push_back((int32_t)p);
         else lists[c].push_back((int32_t)p);
     }
     for (int c = 0; c < kGlsClasses; ++c) {
@@ -389,6 +392,16 @@ int nin_grid_to_device(nin_grid *g, int device) {
         if (d.hex8.count) {   // lane descriptors of the multifrontal kernel, one 16-byte record per list entry
             if ((rc = dev_alloc(d, &d.hex8_desc, (size_t)d.hex8.count * 4))) return rc;
             if (launch_hex8_desc(d.v, d.hex8.nodes, d.hex8.count, d.hex8_desc, nullptr)) return fail(NIN_EHIP, "hex8 descriptor kernel");
+        }
+    }
+    {
+        d.mfw.count = (int32_t)mfw_list.size();
+        const int32_t *lp = nullptr;
+        if (d.mfw.count && (rc = dev_upload(d, &lp, mfw_list))) return rc;
+        d.mfw.nodes = const_cast<int32_t *>(lp);
+        if (d.mfw.count) {   // descriptors of the one-wavefront multifrontal kernel, 32 words per list entry
+            if ((rc = dev_alloc(d, &d.mfw_desc, (size_t)d.mfw.count * kMfwDescWords))) return rc;
+            if (launch_mfw_desc(d.v, d.mfw.nodes, d.mfw.count, d.mfw_desc, nullptr)) return fail(NIN_EHIP, "mfw descriptor kernel");
         }
     }
     d.gls_too_large = rows_max[kGlsClasses - 1] > 1024;
@@ -438,6 +451,12 @@ static int launch_hex8(DeviceGrid &d, const int32_t *nodes, const int32_t *desc,
     return launch_gls_hex8mf(d.v, nodes, desc, count, add_neumann, out, nws, d.gls_queue, stream);
 }
 
+// two-coloured nodes: the one-wavefront multifrontal kernel (work counter: int 5 of the queue block)
+static int launch_mfw(DeviceGrid &d, const int32_t *nodes, const uint32_t *desc, int32_t count, int add_neumann,
+                      double *out, double *nws, hipStream_t stream) {
+    return launch_gls_mfw(d.v, nodes, desc, count, add_neumann, out, nws, d.gls_queue + 5, stream);
+}
+
 // one GLS size class: the block kernel with the system in LDS, or the wave kernel on global scratch
 static int launch_class(DeviceGrid &d, int c, const int32_t *nodes, int32_t count, int add_neumann, double *out,
                         double *nws, hipStream_t stream) {
@@ -472,6 +491,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else {
             HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
             rc = launch_hex8(d, d.hex8.nodes, d.hex8_desc, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
+            if (!rc) rc = launch_mfw(d, d.mfw.nodes, d.mfw_desc, d.mfw.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             for (int c = 0; c < kGlsClasses && !rc; ++c) {
                 rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             }
@@ -485,10 +505,11 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     HIP_TRY(hipMemsetAsync(dev_csr_data, 0, (size_t)d.nnz_e * 8, stream));
     HIP_TRY(hipMemsetAsync(dev_neumann_ws, 0, (size_t)P * 8, stream));
     if (n_targets == 0) return NIN_OK;
-    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 1 : 1);
+    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 2 : 1);
     for (int64_t i = 0; i < n_targets; ++i) {
         int c = method == NIN_METHOD_GLS ? g->node_class[targets[i]] : 0;
-        if (c == 255) c = kGlsClasses;   // the hex8 group-kernel class
+        if (c == 255) c = kGlsClasses;   // the hex8 kernel's class
+        else if (c == 254) c = kGlsClasses + 1;   // the one-wavefront multifrontal kernel's class
         lists[c].push_back((int32_t)targets[i]);
     }
     // one device buffer for all class lists, filled before the first launch: a per-class allocate / copy / free
@@ -503,13 +524,19 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     first[lists.size()] = flat.size();
     int32_t *dl0 = nullptr;
     const size_t n_hex8 = method == NIN_METHOD_GLS ? lists[kGlsClasses].size() : 0;   // + 4 descriptor words per cube node
-    HIP_TRY(hipMalloc((void **)&dl0, (flat.size() + 4 * n_hex8) * 4));
+    const size_t n_mfw = method == NIN_METHOD_GLS ? lists[kGlsClasses + 1].size() : 0;   // + 32 per two-coloured node
+    HIP_TRY(hipMalloc((void **)&dl0, (flat.size() + 4 * n_hex8 + kMfwDescWords * n_mfw) * 4));
     int32_t *ddesc = dl0 + flat.size();
+    uint32_t *dmfw = reinterpret_cast<uint32_t *>(ddesc + 4 * n_hex8);
     const hipError_t cp = hipMemcpy(dl0, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
     if (cp != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemcpy: %s", hipGetErrorString(cp)); }
     if (n_hex8 && launch_hex8_desc(d.v, dl0 + first[kGlsClasses], (int32_t)n_hex8, ddesc, stream)) {
         (void)hipFree(dl0);
         return fail(NIN_EHIP, "hex8 descriptor kernel");
+    }
+    if (n_mfw && launch_mfw_desc(d.v, dl0 + first[kGlsClasses + 1], (int32_t)n_mfw, dmfw, stream)) {
+        (void)hipFree(dl0);
+        return fail(NIN_EHIP, "mfw descriptor kernel");
     }
     if (method == NIN_METHOD_GLS) {
         const hipError_t qe = hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream);
@@ -522,6 +549,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_hex8(d, dl, ddesc, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
+        else if ((int)c == kGlsClasses + 1) rc = launch_mfw(d, dl, dmfw, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else rc = launch_class(d, (int)c, dl, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
     }
     const hipError_t sy = hipStreamSynchronize(stream);   // the lists must outlive the kernels

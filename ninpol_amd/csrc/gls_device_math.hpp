@@ -102,6 +102,52 @@ __device__ __attribute__((noinline)) static double face_tau(double un, double et
     return __builtin_amdgcn_ldexp(q, (int)k);
 }
 
+// Computed HERE: without it the optimiser sinks a value's whole computation down to its first use -- for u, s and z
+// that is the end of the pass, with the rows of R they are made from parked in ~140 AGPRs across phase 2.
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+
+// Apply the three reflectors of the panel (v_k in P[k..9][k], pivot entries included; g[k]) to W columns of the
+// front.  Z0 / ZA / ZB / ZC: which row groups of the columns can be non-zero on entry (row 0, the rows 1-3, 4-6, 7-9
+// of face 0, 1, 2) -- the others are structural zeros that the first reflector fills.
+template <int W, bool Z0, bool ZA, bool ZB, bool ZC>
+__device__ __forceinline__ void apply_panel(const double (&P)[10][3], const double (&g)[3], double (&B)[10][W]) {
+    double w[W];
+    // reflector 0, rows 0..9
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+        double d = 0.0;
+        if (Z0) d = P[0][0] * B[0][c];
+#pragma unroll
+        for (int r = 1; r < 10; ++r) {
+            const bool nz = (r <= 3) ? ZA : (r <= 6) ? ZB : ZC;
+            if (nz) d = fma(P[r][0], B[r][c], d);
+        }
+        w[c] = -(g[0] * d);
+    }
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const bool nz = (r == 0) ? Z0 : (r <= 3) ? ZA : (r <= 6) ? ZB : ZC;
+#pragma unroll
+        for (int c = 0; c < W; ++c) B[r][c] = nz ? fma(w[c], P[r][0], B[r][c]) : w[c] * P[r][0];
+    }
+    // reflectors 1 and 2, rows k..9 (dense by now)
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            double d = P[k][k] * B[k][c];
+#pragma unroll
+            for (int r = k + 1; r < 10; ++r) d = fma(P[r][k], B[r][c], d);
+            w[c] = -(g[k] * d);
+        }
+#pragma unroll
+        for (int r = k; r < 10; ++r) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) B[r][c] = fma(w[c], P[r][k], B[r][c]);
+        }
+    }
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -27,6 +27,7 @@
 #include "device_grid.hpp"
 #include "grid_host.hpp"
 #include "hex8_desc.hpp"
+#include "mfw_desc.hpp"
 #include "launch.hpp"
 
 namespace nin {
@@ -559,9 +560,13 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
     const int64_t ne = g.esup_ptr[p + 1] - g.esup_ptr[p], nf = g.fsup_ptr[p + 1] - g.fsup_ptr[p];
     int64_t nbf = 0;
     for (int32_t q = g.fsup_ptr[p]; q < g.fsup_ptr[p + 1]; ++q) nbf += g.face_cells[2 * (int64_t)g.fsup[q] + 1] == -1;
-    if (use_group && ne == 8 && nf == 12 && nbf == 0 && g.dim == 3) {
+    if ((use_group & 1) && ne == 8 && nf == 12 && nbf == 0 && g.dim == 3) {
         int32_t d[4];   // the hex8 kernel needs the cells to form the cube graph (hex8_desc.hpp)
         if (hex8_descriptor(g, (int32_t)p, d)) { node_class[p] = 255; return; }
+    }
+    if ((use_group & 2) && nbf == 0 && ne <= kMfwMaxFronts + kMfwMaxDense) {
+        uint32_t w[kMfwDescWords];   // bipartite cell graph, fronts with 3 faces each (mfw_desc.hpp)
+        if (mfw_descriptor(g, (int32_t)p, w)) { node_class[p] = 254; return; }
     }
     int64_t bytes, rows, cols;
     const int c = gls_node_class(ne, nf, nbf, force_global != 0, &bytes, &rows, &cols);

@@ -222,6 +222,33 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
 #pragma unroll
             for (int q = 0; q <= TOP; ++q) acc[u & 1][q] = fma(xn, nv[q], acc[u & 1][q]);
         };
+        // a full group, stage by stage across its G rows: a row's chain (broadcast x -> update -> broadcast the new
+        // entry of column k + 1 -> dot) is four dependent instructions deep, the G chains side by side fill each
+        // other's latencies (the compiler, left alone, runs them one after the other through one scalar register pair)
+        auto rows = [&](double (&cur)[G][TOP + 1]) {
+            double x[G], xn[G], nv[G][TOP + 1];
+#pragma unroll
+            for (int u = 0; u < G; ++u) x[u] = readlane_f64(cur[u][TOP], lk);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+#pragma unroll
+                for (int q = 0; q <= TOP; ++q) nv[u][q] = fma(-x[u], w[q], cur[u][q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+#pragma unroll
+                for (int q = 0; q <= TOP; ++q) p[q][u * NW] = nv[u][q];
+                xn[u] = readlane_f64(next_in_top ? nv[u][TOP] : nv[u][TOP > 0 ? TOP - 1 : 0], ln);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+#pragma unroll
+                for (int q = 0; q <= TOP; ++q) acc[u & 1][q] = fma(xn[u], nv[u][q], acc[u & 1][q]);
+            }
+        };
         if (full > 0) {
             double cur[G][TOP + 1];
 #pragma unroll
@@ -236,8 +263,7 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
 #pragma unroll
                     for (int q = 0; q <= TOP; ++q) nx[u][q] = p[q][(G + u) * NW];
                 }
-#pragma unroll
-                for (int u = 0; u < G; ++u) row(u, cur);
+                rows(cur);
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
 #pragma unroll
@@ -246,8 +272,7 @@ __device__ __forceinline__ void qr_step(const Sys &s, int k, int buf, double (&d
 #pragma unroll
                 for (int q = 0; q <= TOP; ++q) p[q] += G * NW;
             }
-#pragma unroll
-            for (int u = 0; u < G; ++u) row(u, cur);
+            rows(cur);
 #pragma unroll
             for (int q = 0; q <= TOP; ++q) p[q] += G * NW;
         }
@@ -447,6 +472,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
 #else
         s.stamps = nullptr;
 #endif
+        NIN_STAMP(s, 200, 0);                                    // coarse timeline of the node: K = 200, 201
         constexpr int AUXW = NW == 1 ? 2 : (DB ? 2 : 1) * NW;   // the partial-dot buffers: AUXW * n doubles
         int32_t *cells = reinterpret_cast<int32_t *>(s.aux + AUXW * n);
         uint8_t *cpos = reinterpret_cast<uint8_t *>(cells + 2 * ((ne + 1) >> 1));   // [ne] column block of a cell (SPARSE)
@@ -695,6 +721,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
         }
         }
         group_sync<NW>();
+        NIN_STAMP(s, 200, 1);                                    // plan + assembly done
 
         // ---- phase 1 (SPARSE): the fronts of the independent cells, a wave each, no barrier between them -------------
         int R0 = 0;
@@ -709,6 +736,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             const int nlive = n - R0;
             if (!DB && 2 * NW * nlive <= AUXW * n) { s.db = true; s.pstride = nlive; }
         }
+        NIN_STAMP(s, 200, 2);                                    // fronts done
 
         // ---- Householder QR of the remaining columns R0 .. n-2, the last one carried along ---------------------------
         bool singular = false;
@@ -729,6 +757,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
                 if (lane + 64 * q < s.pstride) P[lane + 64 * q] = dn[q];
             group_sync<NW>();
         }
+        NIN_STAMP(s, 200, 3);                                    // first dots published
         for (int k = R0; k < n - 1; ++k) {
             if (k > R0 && wave == (k - 1) % NW) {   // row k-1 of R: every wave has finished reading it as a pivot row
 #pragma unroll
@@ -751,6 +780,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             if (lane <= 1) s.A[(n - 1 - lane) * ld + (n - 2)] = rkeep[0];
         }
         group_sync<NW>();
+        NIN_STAMP(s, 201, 0);                                    // dense steps done
 
         // ---- tail, wave 0: R y = c~(0:n-1) by columns (lane = row), then the residual ------------------------
         if (wave == 0) {
@@ -834,6 +864,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
             const double nwv = is_neu ? wrow[ne - 1] : 0.0;
             const double add = add_neumann ? nwv : 0.0;
             for (int i = lane; i < ne; i += 64) out[eb + i] = wrow[i] + add;
+            NIN_STAMP(s, 201, 1);                                // weights stored
 #ifdef NIN_BLOCK_STAMPS
             if (lane == 0 && (dbg >> 8) == 0) nws[p] = nwv;
 #else

@@ -1,0 +1,380 @@
+// kernels_gls_mfw.hip -- GLS weights of "two-coloured" nodes (mfw_desc.hpp: interior nodes of Kuhn-type tetrahedron
+// meshes, of wedge meshes, ...), gfx950: ONE wavefront per node, the whole factorisation in registers.
+//
+// The system (gls.pyx:252-356) as in kernels_gls_hex8mf.hip: unknowns = a gradient per cell (3 columns) + the node
+// value (the column c that the last-row identity turns into a right-hand side); rows = one per cell and three per
+// internal face, a face row coupling exactly its two cells.  The cell graph is bipartite here: F "front" cells that
+// share no face (each with exactly 3 faces at the node) and D "dense" cells; every face joins a front to a dense cell.
+//
+//   phase 1  lane f < F = front f: the 3 Householder steps on the front cell's own columns touch only its 10 rows
+//            (cell row + 3 x 3 face rows) -- all F fronts at once, one per lane, no cross-lane traffic, exactly as the
+//            quad lanes of the hex8 kernel do it.  Each leaves 3 rows of R, folded at once into what the weights need
+//            of them (z = R_ee^-T d_e, u = z^T R_ed, s = z . b_e), and 7 fill rows over the 9 columns of its three
+//            dense neighbours + c, which go through LDS into
+//   phase 2  the dense (7 F + D) x (3 D + 1) problem -- Kuhn tetrahedra: 96 x 37 -- with lane = COLUMN and every row a
+//            register pair of the wavefront: a Householder step broadcasts the pivot column entry of a row with
+//            v_readlane, updates the row, and in the same pass accumulates the next pivot column's dots.  No LDS, no
+//            barrier, no partial sums: the block kernel spends 4 wavefronts, an LDS round trip per row and two
+//            workgroup barriers per step on the same sweep, and ~3 x the instructions.  Retired rows are zeroed in
+//            place (a zero row is invisible to every later reflector), so the step loop is a run-time loop over one
+//            body; blocks of 8 rows that have retired altogether are skipped;
+//   then     R y = Q^T c by columns (lane = row, R through LDS), r_i = 1 - d_i . y_i per cell, weights r_i / (r . r)
+//            (the identity X[n-1, i] = r_i / (r.r)).
+// Same mathematics as dgels on the reference's matrix -- a Householder QR in a column order that exposes the zeros.
+// Two wavefronts per SIMD (<= 256 registers), 8 nodes in flight per CU against 2 for the block kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "device_grid.hpp"
+#include "gls_device_math.hpp"
+#include "launch.hpp"
+#include "mfw_desc.hpp"
+
+namespace nin {
+
+namespace {
+
+using namespace glsmath;
+
+constexpr int ROWS = 7 * kMfwMaxFronts + kMfwMaxDense;   // 96 dense rows: 7 fill rows per front, then the dense cells' rows
+constexpr int DROW0 = 7 * kMfwMaxFronts;                 // first dense-cell row
+constexpr int NCMAX = 3 * kMfwMaxDense + 1;              // 37 dense columns (c last)
+constexpr int RP = NCMAX;                                // pitch of a stored row of R
+constexpr int STAGE_F = 70;                              // per front: 7 fill rows x (9 neighbour columns + c)
+constexpr int LDS_R = (NCMAX - 1) * RP;                  // 36 rows of R (the fill-row staging area of phase 1 lies under it)
+constexpr int LDS_Y = LDS_R, LDS_D = LDS_Y + 40, LDS_W = LDS_D + 40, LDS_PER_WAVE = LDS_W + 24;
+static_assert(kMfwMaxFronts * STAGE_F <= LDS_R, "staging area");
+
+__device__ __forceinline__ double rl64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint32_t rl32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+
+// the pivot row of step t leaves the register file (and is zeroed there: retired)
+#define NIN_MFW_CASE(R) case R: rowk = a[R]; a[R] = 0.0; break;
+#define NIN_MFW_CASES4(R) NIN_MFW_CASE(R) NIN_MFW_CASE(R + 1) NIN_MFW_CASE(R + 2) NIN_MFW_CASE(R + 3)
+#define NIN_MFW_CASES12(R) NIN_MFW_CASES4(R) NIN_MFW_CASES4(R + 4) NIN_MFW_CASES4(R + 8)
+
+__global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
+                                                              const uint32_t *__restrict__ desc, int32_t count,
+                                                              int add_neumann, double *__restrict__ out,
+                                                              double *__restrict__ nws, int32_t *__restrict__ queue) {
+    __shared__ double lds_all[4][LDS_PER_WAVE];
+    const int lane = threadIdx.x & 63;
+    double *const Rm = lds_all[threadIdx.x >> 6];
+    double *const yb = Rm + LDS_Y, *const dbuf = Rm + LDS_D, *const wbuf = Rm + LDS_W;
+    const int sc = (lane * 43) >> 7, tc = lane - 3 * sc;          // this lane's dense column = component tc of dense slot sc
+
+    auto ticket = [&]() -> int32_t {
+        int32_t v = 0;
+        if (lane == 0) v = atomicAdd(queue, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    for (int32_t idx = ticket(); idx < count; idx = ticket()) {
+        const int32_t p = __builtin_amdgcn_readfirstlane(nodes ? nodes[idx] : idx);
+        const uint32_t *dw = desc + (size_t)kMfwDescWords * idx;
+        const uint32_t fd = (uint32_t)__builtin_amdgcn_readfirstlane((int)dw[24]);
+        const int F = fd & 255, D = (fd >> 8) & 255;
+        const int fl = lane < kMfwMaxFronts ? lane : 0;
+        const uint32_t w0 = dw[fl], w1 = dw[12 + fl];
+        const uint32_t eb = (uint32_t)__builtin_amdgcn_readfirstlane(g.esup_ptr[p]);
+        const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane(g.fsup_ptr[p]);
+        const bool is_neu = (__builtin_amdgcn_readfirstlane((int)g.flags[p]) & 2) != 0;
+        const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1], xv2 = g.coords[3 * (size_t)p + 2];
+        const uint32_t pe = w0 & 31, po = (w0 >> 21) & 31;
+        const uint32_t frec[3] = {(w0 >> 5) & 0xFFFFu, w1 & 0xFFFFu, w1 >> 16};
+
+        // ---- phase 1: the front of cell E_f in lane f (rows 0 = cell row, 1 + 3 i + r = row r of face i) -------------
+        double u[9], se, de[3], dod[3];
+        {
+            const uint32_t ce = (uint32_t)g.esup[eb + pe], co = (uint32_t)g.esup[eb + po];
+            double P[10][3], nb0[3][3], sav[3][2][3];
+            double Ke[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Ke[k] = g.perm[9 * (size_t)ce + k];
+            const double dme = g.diff_mag[ce];
+            de[0] = g.centroids[3 * (size_t)ce + 0] - xv0;      // gls.pyx:269-277
+            de[1] = g.centroids[3 * (size_t)ce + 1] - xv1;
+            de[2] = g.centroids[3 * (size_t)ce + 2] - xv2;
+            dod[0] = g.centroids[3 * (size_t)co + 0] - xv0;
+            dod[1] = g.centroids[3 * (size_t)co + 1] - xv1;
+            dod[2] = g.centroids[3 * (size_t)co + 2] - xv2;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) P[0][t] = de[t];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                // B = [K N; T1; tau T2] (gls.pyx:293-321), row = [-B_a | +B_b] (gls.pyx:340-356)
+                const uint32_t f = (uint32_t)g.fsup[fb + (frec[i] & 63)];
+                const uint32_t cn = (uint32_t)g.esup[eb + ((frec[i] >> 11) & 31)];
+                const double N0 = (double)g.face_normal[3 * (size_t)f + 0], N1 = (double)g.face_normal[3 * (size_t)f + 1],
+                             N2 = (double)g.face_normal[3 * (size_t)f + 2];
+                const double T0 = xv0 - g.face_center[3 * (size_t)f + 0], T1 = xv1 - g.face_center[3 * (size_t)f + 1],
+                             T2 = xv2 - g.face_center[3 * (size_t)f + 2];
+                const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+                const double dmn = g.diff_mag[cn];
+                double eta = 0.0;
+                eta = dme > eta ? dme : eta;
+                eta = dmn > eta ? dmn : eta;
+                const double tj = face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
+                const double sg = ((frec[i] >> 10) & 1) ? -1.0 : 1.0;
+                const double *Kn = g.perm + 9 * (size_t)cn;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    P[1 + 3 * i][t] = sg * (Ke[t * 3 + 0] * N0 + Ke[t * 3 + 1] * N1 + Ke[t * 3 + 2] * N2);
+                    nb0[i][t] = -sg * (Kn[t * 3 + 0] * N0 + Kn[t * 3 + 1] * N1 + Kn[t * 3 + 2] * N2);
+                }
+                sav[i][0][0] = sg * T0; sav[i][0][1] = sg * T1; sav[i][0][2] = sg * T2;
+                sav[i][1][0] = sg * (tj * U0); sav[i][1][1] = sg * (tj * U1); sav[i][1][2] = sg * (tj * U2);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { P[2 + 3 * i][t] = sav[i][0][t]; P[3 + 3 * i][t] = sav[i][1][t]; }
+            }
+            // panel: three Householder steps on the own columns; v_k stays in P[k..9][k]
+            double g3[3], rinv[3], z[3];
+            {
+                double ss = 0.0;
+#pragma unroll
+                for (int r = 1; r < 10; ++r) ss = fma(P[r][0], P[r][0], ss);
+                const House h = house_unguarded(P[0][0], ss);
+                g3[0] = h.g; rinv[0] = h.rinv;
+                double d1 = h.vp * P[0][1], d2 = h.vp * P[0][2];
+#pragma unroll
+                for (int r = 1; r < 10; ++r) { d1 = fma(P[r][0], P[r][1], d1); d2 = fma(P[r][0], P[r][2], d2); }
+                const double w1 = -(h.g * d1), w2 = -(h.g * d2);
+                P[0][0] = h.vp;
+#pragma unroll
+                for (int r = 0; r < 10; ++r) { P[r][1] = fma(w1, P[r][0], P[r][1]); P[r][2] = fma(w2, P[r][0], P[r][2]); }
+            }
+            {
+                double ss = 0.0;
+#pragma unroll
+                for (int r = 2; r < 10; ++r) ss = fma(P[r][1], P[r][1], ss);
+                const House h = house_unguarded(P[1][1], ss);
+                g3[1] = h.g; rinv[1] = h.rinv;
+                double d2 = h.vp * P[1][2];
+#pragma unroll
+                for (int r = 2; r < 10; ++r) d2 = fma(P[r][1], P[r][2], d2);
+                const double w2 = -(h.g * d2);
+                P[1][1] = h.vp;
+#pragma unroll
+                for (int r = 1; r < 10; ++r) P[r][2] = fma(w2, P[r][1], P[r][2]);
+            }
+            {
+                double ss = 0.0;
+#pragma unroll
+                for (int r = 3; r < 10; ++r) ss = fma(P[r][2], P[r][2], ss);
+                const House h = house_unguarded(P[2][2], ss);
+                g3[2] = h.g; rinv[2] = h.rinv;
+                P[2][2] = h.vp;
+            }
+            // z = R_ee^-T d_e: all the weights need of the front cell's three rows of R
+            z[0] = de[0] * rinv[0];
+            z[1] = fma(-P[0][1], z[0], de[1]) * rinv[1];
+            z[2] = fma(-P[1][2], z[1], fma(-P[0][2], z[0], de[2])) * rinv[2];
+            // the reflectors on c and on the three neighbour blocks; rows 0..2 -> s, u; rows 3..9 -> the staging area
+            double *stg = Rm + (lane < F ? lane : 0) * STAGE_F;
+            const bool front_lane = lane < F;
+            {
+                double Bc[10][1];
+                Bc[0][0] = 1.0;                               // c = e_0 on entry: only the cell row carries a 1
+                apply_panel<1, true, false, false, false>(P, g3, Bc);
+                se = fma(z[2], Bc[2][0], fma(z[1], Bc[1][0], z[0] * Bc[0][0]));
+                if (front_lane) {
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) stg[r * 10 + 9] = Bc[3 + r][0];
+                }
+            }
+#define NIN_MFW_BLOCK(I, ZA, ZB, ZC)                                                                      \
+            {                                                                                             \
+                double B[10][3];                                                                          \
+                _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                           \
+                    B[1 + 3 * I][t] = nb0[I][t]; B[2 + 3 * I][t] = -sav[I][0][t]; B[3 + 3 * I][t] = -sav[I][1][t]; \
+                }                                                                                         \
+                apply_panel<3, false, ZA, ZB, ZC>(P, g3, B);                                              \
+                _Pragma("unroll") for (int t = 0; t < 3; ++t)                                             \
+                    u[3 * I + t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));                \
+                if (front_lane) {                                                                         \
+                    _Pragma("unroll") for (int r = 0; r < 7; ++r)                                         \
+                        _Pragma("unroll") for (int t = 0; t < 3; ++t) stg[r * 10 + 3 * I + t] = B[3 + r][t]; \
+                }                                                                                         \
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            NIN_MFW_BLOCK(0, true, false, false)
+            __builtin_amdgcn_sched_barrier(0);
+            NIN_MFW_BLOCK(1, false, true, false)
+            __builtin_amdgcn_sched_barrier(0);
+            NIN_MFW_BLOCK(2, false, false, true)
+#undef NIN_MFW_BLOCK
+        }
+        // the dense cells' rows, (x_K - x_v) on the cell's own columns: column 3 d + t <- lane d's component t
+        if (lane < D) { dbuf[3 * lane + 0] = dod[0]; dbuf[3 * lane + 1] = dod[1]; dbuf[3 * lane + 2] = dod[2]; }
+        wave_lds_sync();
+
+        // ---- the dense problem: row r in the register pair a[r], lane = column ------------------------------------------
+        const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
+        const bool is_rhs = lane == nc;
+        double a[ROWS];
+        {
+#pragma unroll
+            for (int f = 0; f < kMfwMaxFronts; ++f) {
+                int j = -1;
+                if (f < F) {
+                    const uint32_t q0 = rl32(w0, f), q1 = rl32(w1, f);
+                    const int s0 = (q0 >> 11) & 15, s1 = (q1 >> 6) & 15, s2 = (q1 >> 22) & 15;   // dense slots of the front's 3 neighbours
+                    j = sc == s0 ? tc : j;
+                    j = sc == s1 ? 3 + tc : j;
+                    j = sc == s2 ? 6 + tc : j;
+                    j = lane < nc ? j : -1;
+                    j = is_rhs ? 9 : j;
+                }
+                const double *src = Rm + f * STAGE_F + (j >= 0 ? j : 0);
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    double v = 0.0;
+                    if (j >= 0) v = src[r * 10];
+                    a[7 * f + r] = v;
+                }
+            }
+            const double dodv = dbuf[lane < 3 * kMfwMaxDense ? lane : 0];
+#pragma unroll
+            for (int d = 0; d < kMfwMaxDense; ++d) {
+                double v = (sc == d && lane < nc) ? dodv : 0.0;
+                v = is_rhs ? 1.0 : v;
+                a[DROW0 + d] = d < D ? v : 0.0;
+            }
+        }
+        wave_lds_sync();          // the staging area is R's from here on
+
+        double dd;                 // dots of the pivot column with every column (lane = column)
+        {
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r += 2) {
+                const double x0 = rl64(a[r], 0), x1 = rl64(a[r + 1], 0);
+                acc0 = fma(x0, a[r], acc0);
+                acc1 = fma(x1, a[r + 1], acc1);
+            }
+            dd = acc0 + acc1;
+        }
+        for (int t = 0; t < nc; ++t) {
+            double rowk = 0.0;
+            switch (t) {
+                NIN_MFW_CASES12(0) NIN_MFW_CASES12(12) NIN_MFW_CASES12(24)
+                default: break;
+            }
+            const double dk = rl64(dd, t), alpha = rl64(rowk, t);
+            const double sq = dk * fast_rsqrt(dk);                   // |(alpha, x)|
+            const double beta = -copysign(sq, alpha);
+            const double inv = fast_rcp(fma(fabs(alpha), sq, dk));   // 1 / (beta (beta - alpha))
+            const double vk = alpha - beta;
+            const double w = lane > t ? (dd - beta * rowk) * inv : 0.0;
+            double rrow = fma(-vk, w, rowk);                          // row t of R
+            rrow = lane == t ? beta : rrow;
+            rrow = lane < t ? 0.0 : rrow;
+            if (lane < RP) Rm[t * RP + lane] = rrow;
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int b = 0; b < ROWS / 8; ++b) {
+                if (8 * b + 7 <= t) continue;                        // (wave-uniform) these 8 rows have all retired
+                double x[8], xn[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = rl64(a[8 * b + q], t);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[8 * b + q] = fma(-x[q], w, a[8 * b + q]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xn[q] = rl64(a[8 * b + q], t + 1);
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    acc0 = fma(xn[q], a[8 * b + q], acc0);
+                    acc1 = fma(xn[q + 1], a[8 * b + q + 1], acc1);
+                }
+            }
+            dd = acc0 + acc1;
+        }
+        const double rr = rl64(dd, nc);                               // r . r = |(Q^T c)(nc:)|^2
+        wave_lds_sync();
+
+        // ---- R y = (Q^T c)(0:nc) by columns: lane = row ------------------------------------------------------------------
+        {
+            const int li = lane < nc ? lane : 0;
+            double ct = lane < nc ? Rm[li * RP + nc] : 0.0;
+            const double ri = fast_rcp(Rm[li * RP + li]);
+            double coln = lane < nc ? Rm[li * RP + (nc - 1)] : 0.0;
+            for (int k = nc - 1; k >= 0; --k) {
+                const double col = lane <= k ? coln : 0.0;
+                if (k > 0) coln = lane < nc ? Rm[li * RP + (k - 1)] : 0.0;
+                const double yk = rl64(ct * ri, k);
+                ct = lane < k ? fma(-yk, col, ct) : ct;
+            }
+            if (lane < nc) yb[lane] = ct * ri;
+        }
+        wave_lds_sync();
+        // ---- residuals on the cell rows, weights ---------------------------------------------------------------------------
+        {
+            double re = 1.0 - se;                                     // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_dense
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int s = (frec[i] >> 6) & 15;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) re = fma(u[3 * i + t], yb[3 * s + t], re);
+            }
+            const int ld = lane < D ? lane : 0;
+            const double ro = 1.0 - fma(dod[2], yb[3 * ld + 2], fma(dod[1], yb[3 * ld + 1], dod[0] * yb[3 * ld]));
+            const double rri = fast_rcp(rr);
+            double we = re * rri, wo = ro * rri;
+            // rank-deficient system (or NaN from a zero column): undefined in the reference, the zero row here
+            const bool ok = rr > 0.0;
+            we = (ok && __builtin_isfinite(we)) ? we : 0.0;
+            wo = (ok && __builtin_isfinite(wo)) ? wo : 0.0;
+            if (lane < F) wbuf[pe] = we;
+            if (lane < D) wbuf[po] = wo;
+        }
+        wave_lds_sync();
+        {
+            const int ne = F + D;
+            // gls.pyx:470-472 (only if an interior node carries the Neumann flag): neumann_ws = the last cell's weight
+            const double nwv = is_neu ? wbuf[ne - 1] : 0.0;
+            const double addv = add_neumann ? nwv : 0.0;
+            if (lane < ne) out[eb + lane] = wbuf[lane] + addv;
+            if (lane == 0) nws[p] = nwv;
+        }
+        wave_lds_sync();
+    }
+}
+
+__global__ void k_mfw_desc(GridView g, const int32_t *__restrict__ nodes, int32_t count, uint32_t *__restrict__ desc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w[kMfwDescWords];
+    if (!mfw_descriptor(g, nodes ? nodes[i] : (int32_t)i, w)) {   // (the list holds classified nodes only)
+#pragma unroll
+        for (int k = 0; k < kMfwDescWords; ++k) w[k] = 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kMfwDescWords; ++k) desc[kMfwDescWords * i + k] = w[k];
+}
+
+}  // namespace
+
+int launch_mfw_desc(const GridView &g, const int32_t *nodes, int32_t count, uint32_t *desc, hipStream_t stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_mfw_desc, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, stream, g, nodes, count, desc);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int add_neumann,
+                   double *out, double *nws, int32_t *queue, hipStream_t stream) {
+    if (count <= 0) return 0;
+    int64_t blocks = ((int64_t)count + 3) / 4;
+    const int64_t cap = 2 * 256;   // <= 256 registers per lane: two 4-wave workgroups per CU are resident; persistent
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(nin_gls_mfw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count, add_neumann,
+                       out, nws, queue);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+const char *kernel_name_gls_mfw() { return "nin_gls_mfw_kernel"; }
+
+}  // namespace nin

@@ -70,3 +70,33 @@ def test_lin_exact_oracle(oracle_lib):
     for meth in ("gls", "idw", "ls"):
         W, _ = o.interpolate("LIN", meth)
         assert l2_internal(W, u, exact, internal) < 1e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["QUAD", "FAN", "ALH"])
+def test_published_accuracy_gpu(case):
+    """The same published numbers through the HIP path and the C-ABI -- no oracle in between -- at all four mesh sizes
+    the reference lists (n = 4 .. 32), and the device-side apply beside the scipy product."""
+    import ninpol_amd
+    for i, n in enumerate(SIZES):
+        mesh, u, exact, internal = make_case(case, n)
+        I = ninpol_amd.Interpolator()
+        I.load_mesh(mesh_obj=mesh)
+        for meth in ("gls", "idw", "ls"):
+            W, _ = I.interpolate(case, meth)
+            err = l2_internal(W, u, exact, internal)
+            assert err == pytest.approx(PUBLISHED[case][meth][i], rel=1e-9), (case, n, meth)
+            vals = np.asarray(I.apply(case, meth, u)[0])
+            e2 = np.sqrt(np.sum((vals[internal] - exact[internal]) ** 2) / np.sum(exact[internal] ** 2))
+            assert e2 == pytest.approx(PUBLISHED[case][meth][i], rel=1e-9), (case, n, meth, "apply")
+
+
+@pytest.mark.gpu
+def test_lin_exact_gpu():
+    import ninpol_amd
+    mesh, u, exact, internal = make_case("LIN", 16)
+    I = ninpol_amd.Interpolator()
+    I.load_mesh(mesh_obj=mesh)
+    for meth in ("gls", "idw", "ls"):
+        W, _ = I.interpolate("LIN", meth)
+        assert l2_internal(W, u, exact, internal) < 1e-13

@@ -12,7 +12,7 @@ for name in (sys.argv[1:] or [c for c in cases if not c.endswith(("10m", "80m", 
     m = cases[name](); M.attach_fields(m, "u", perm="ALH")
     I = ninpol_amd.Interpolator(grid_build=os.environ.get("NIN_GRID_BUILD", "host")); t0 = time.time(); I.load_mesh(mesh_obj=m); print(f"{name}: load_mesh {time.time() - t0:.2f} s")
     st = torch.cuda.current_stream()
-    for meth in ("idw", "ls", "gls"):
+    for meth in os.environ.get("NIN_METHODS", "idw,ls,gls").split(","):
         plan = I.device_plan("u", meth)
         out = torch.empty(plan.nnz, dtype=torch.float64, device="cuda"); nws = torch.empty(plan.n_points, dtype=torch.float64, device="cuda")
         plan.launch(out.data_ptr(), nws.data_ptr(), st.cuda_stream); torch.cuda.synchronize()
