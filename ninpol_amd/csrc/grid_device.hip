@@ -566,7 +566,11 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
     }
     if ((use_group & 2) && nbf == 0 && ne <= kMfwMaxFronts + kMfwMaxDense) {
         uint32_t w[kMfwDescWords];   // bipartite cell graph, fronts with 3 faces each (mfw_desc.hpp)
-        if (mfw_descriptor(g, (int32_t)p, w)) { node_class[p] = 254; return; }
+        if (mfw_descriptor(g, (int32_t)p, w)) {
+            const int F = w[24] & 255, D = (w[24] >> 8) & 255;
+            node_class[p] = (F <= kMfwSmallFronts && D <= kMfwSmallDense) ? 253 : 254;
+            return;
+        }
     }
     int64_t bytes, rows, cols;
     const int c = gls_node_class(ne, nf, nbf, force_global != 0, &bytes, &rows, &cols);

@@ -11,13 +11,13 @@
 //            quad lanes of the hex8 kernel do it.  Each leaves 3 rows of R, folded at once into what the weights need
 //            of them (z = R_ee^-T d_e, u = z^T R_ed, s = z . b_e), and 7 fill rows over the 9 columns of its three
 //            dense neighbours + c, which go through LDS into
-//   phase 2  the dense (7 F + D) x (3 D + 1) problem -- Kuhn tetrahedra: 96 x 37 -- with lane = COLUMN and every row a
-//            register pair of the wavefront: a Householder step broadcasts the pivot column entry of a row with
-//            v_readlane, updates the row, and in the same pass accumulates the next pivot column's dots.  No LDS, no
-//            barrier, no partial sums: the block kernel spends 4 wavefronts, an LDS round trip per row and two
-//            workgroup barriers per step on the same sweep, and ~3 x the instructions.  Retired rows are zeroed in
-//            place (a zero row is invisible to every later reflector), so the step loop is a run-time loop over one
-//            body; blocks of 8 rows that have retired altogether are skipped;
+//   phase 2  the dense (7 F + D) x (3 D + 1) problem -- Kuhn tetrahedra: 96 x 37 -- with lane = COLUMN: a Householder
+//            step broadcasts the pivot column entry of a row with v_readlane, updates the row, and in the same pass
+//            accumulates the next pivot column's dots.  The rows that never become pivot rows (60 of the 96) are
+//            register pairs of the wavefront; the 3 D pivot rows live in LDS, where row t of R replaces pivot row t
+//            in place and only the rows still waiting for their turn are swept.  No barrier, no partial sums, one
+//            wavefront's instruction stream: the block kernel spends 4 wavefronts, an LDS round trip per row and two
+//            workgroup barriers per step on the same sweep, and ~3 x the instructions;
 //   then     R y = Q^T c by columns (lane = row, R through LDS), r_i = 1 - d_i . y_i per cell, weights r_i / (r . r)
 //            (the identity X[n-1, i] = r_i / (r.r)).
 // Same mathematics as dgels on the reference's matrix -- a Householder QR in a column order that exposes the zeros.
@@ -37,14 +37,19 @@ namespace {
 
 using namespace glsmath;
 
-constexpr int ROWS = 7 * kMfwMaxFronts + kMfwMaxDense;   // 96 dense rows: 7 fill rows per front, then the dense cells' rows
-constexpr int DROW0 = 7 * kMfwMaxFronts;                 // first dense-cell row
-constexpr int NCMAX = 3 * kMfwMaxDense + 1;              // 37 dense columns (c last)
-constexpr int RP = NCMAX;                                // pitch of a stored row of R
-constexpr int STAGE_F = 70;                              // per front: 7 fill rows x (9 neighbour columns + c)
-constexpr int LDS_R = (NCMAX - 1) * RP;                  // 36 rows of R (the fill-row staging area of phase 1 lies under it)
-constexpr int LDS_Y = LDS_R, LDS_D = LDS_Y + 40, LDS_W = LDS_D + 40, LDS_PER_WAVE = LDS_W + 24;
-static_assert(kMfwMaxFronts * STAGE_F <= LDS_R, "staging area");
+constexpr int STAGE_F = 70;   // per front: 7 fill rows x (9 neighbour columns + c)
+
+// Sizes for nodes with at most FM fronts and DM dense cells: 7 FM + DM dense rows -- the first NP = 3 DM of them (the
+// ones that get pivoted) live in LDS, where row t of R replaces pivot row t in place; the other NREG in registers.
+template <int FM, int DM>
+struct MfwDims {
+    static constexpr int NP = 3 * DM, NREG = 7 * FM - 2 * DM, DROW0 = 7 * FM, RP = 3 * DM + 1;
+    static constexpr int PAD = 8;   // zero rows behind the pivot rows: the LDS sweep runs in whole groups of 4 and reads one group ahead
+    static constexpr int LDS_R = ((NP + PAD) * RP > FM * STAGE_F ? (NP + PAD) * RP : FM * STAGE_F);   // R rows; phase 1's staging area lies under them
+    static constexpr int LDS_Y = LDS_R, LDS_D = LDS_Y + 3 * DM + 4, LDS_W = LDS_D + 3 * DM + 4, LDS_Z = LDS_W + FM + DM,
+                         LDS_PER_WAVE = LDS_Z + 64;   // (LDS_Z: 64 zeros, what a lane without an entry in a fill row reads)
+    static_assert(NREG > 0 && NP % 2 == 0, "row split");
+};
 
 __device__ __forceinline__ double rl64(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -53,19 +58,18 @@ __device__ __forceinline__ double rl64(double v, int lane) {
 }
 __device__ __forceinline__ uint32_t rl32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
-// the pivot row of step t leaves the register file (and is zeroed there: retired)
-#define NIN_MFW_CASE(R) case R: rowk = a[R]; a[R] = 0.0; break;
-#define NIN_MFW_CASES4(R) NIN_MFW_CASE(R) NIN_MFW_CASE(R + 1) NIN_MFW_CASE(R + 2) NIN_MFW_CASE(R + 3)
-#define NIN_MFW_CASES12(R) NIN_MFW_CASES4(R) NIN_MFW_CASES4(R + 4) NIN_MFW_CASES4(R + 8)
-
+template <int FM, int DM>
 __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                               const uint32_t *__restrict__ desc, int32_t count,
                                                               int add_neumann, double *__restrict__ out,
                                                               double *__restrict__ nws, int32_t *__restrict__ queue) {
-    __shared__ double lds_all[4][LDS_PER_WAVE];
+    using Dm = MfwDims<FM, DM>;
+    constexpr int NP = Dm::NP, NREG = Dm::NREG, RP = Dm::RP;
+    __shared__ double lds_all[4][Dm::LDS_PER_WAVE];
     const int lane = threadIdx.x & 63;
     double *const Rm = lds_all[threadIdx.x >> 6];
-    double *const yb = Rm + LDS_Y, *const dbuf = Rm + LDS_D, *const wbuf = Rm + LDS_W;
+    double *const yb = Rm + Dm::LDS_Y, *const dbuf = Rm + Dm::LDS_D, *const wbuf = Rm + Dm::LDS_W;
+    Rm[Dm::LDS_Z + lane] = 0.0;
     const int sc = (lane * 43) >> 7, tc = lane - 3 * sc;          // this lane's dense column = component tc of dense slot sc
 
     auto ticket = [&]() -> int32_t {
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         const uint32_t *dw = desc + (size_t)kMfwDescWords * idx;
         const uint32_t fd = (uint32_t)__builtin_amdgcn_readfirstlane((int)dw[24]);
         const int F = fd & 255, D = (fd >> 8) & 255;
-        const int fl = lane < kMfwMaxFronts ? lane : 0;
+        const int fl = lane < FM ? lane : 0;
         const uint32_t w0 = dw[fl], w1 = dw[12 + fl];
         const uint32_t eb = (uint32_t)__builtin_amdgcn_readfirstlane(g.esup_ptr[p]);
         const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane(g.fsup_ptr[p]);
@@ -212,86 +216,130 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         if (lane < D) { dbuf[3 * lane + 0] = dod[0]; dbuf[3 * lane + 1] = dod[1]; dbuf[3 * lane + 2] = dod[2]; }
         wave_lds_sync();
 
-        // ---- the dense problem: row r in the register pair a[r], lane = column ------------------------------------------
+        // ---- the dense problem, lane = column: rows 0 .. NP-1 (fill rows of the first fronts) go to LDS, the others
+        //      stay in the register pairs a[] ---------------------------------------------------------------------------------
         const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
         const bool is_rhs = lane == nc;
-        double a[ROWS];
+        double a[NREG];
         {
+            double top[NP];
+            const double dodv = dbuf[lane < 3 * DM ? lane : 0];
 #pragma unroll
-            for (int f = 0; f < kMfwMaxFronts; ++f) {
-                int j = -1;
-                if (f < F) {
-                    const uint32_t q0 = rl32(w0, f), q1 = rl32(w1, f);
-                    const int s0 = (q0 >> 11) & 15, s1 = (q1 >> 6) & 15, s2 = (q1 >> 22) & 15;   // dense slots of the front's 3 neighbours
-                    j = sc == s0 ? tc : j;
-                    j = sc == s1 ? 3 + tc : j;
-                    j = sc == s2 ? 6 + tc : j;
-                    j = lane < nc ? j : -1;
-                    j = is_rhs ? 9 : j;
+            for (int row = 0; row < NP + NREG; ++row) {
+                double v = 0.0;
+                if (row < 7 * FM) {
+                    const int f = row / 7, r = row % 7;
+                    // (the slot computation below is the same for the 7 rows of a front: the compiler keeps one copy)
+                    int j = -1;
+                    if (f < F) {
+                        const uint32_t q0 = rl32(w0, f), q1 = rl32(w1, f);
+                        const int s0 = (q0 >> 11) & 15, s1 = (q1 >> 6) & 15, s2 = (q1 >> 22) & 15;   // dense slots of the front's 3 neighbours
+                        j = sc == s0 ? tc : j;
+                        j = sc == s1 ? 3 + tc : j;
+                        j = sc == s2 ? 6 + tc : j;
+                        j = lane < nc ? j : -1;
+                        j = is_rhs ? 9 : j;
+                    }
+                    const double *src = j >= 0 ? Rm + f * STAGE_F + j : Rm + Dm::LDS_Z;
+                    v = src[r * 10];
+                } else {
+                    const int d = row - 7 * FM;                // the cell row of dense cell d: (x_K - x_v) on its own columns, c = 1
+                    v = (sc == d && lane < nc) ? dodv : 0.0;
+                    v = is_rhs ? 1.0 : v;
+                    v = d < D ? v : 0.0;
                 }
-                const double *src = Rm + f * STAGE_F + (j >= 0 ? j : 0);
-#pragma unroll
-                for (int r = 0; r < 7; ++r) {
-                    double v = 0.0;
-                    if (j >= 0) v = src[r * 10];
-                    a[7 * f + r] = v;
-                }
+                if (row < NP) top[row] = v; else a[row - NP] = v;
             }
-            const double dodv = dbuf[lane < 3 * kMfwMaxDense ? lane : 0];
+            wave_lds_sync();          // the staging area is R's from here on
+            if (lane < RP) {
 #pragma unroll
-            for (int d = 0; d < kMfwMaxDense; ++d) {
-                double v = (sc == d && lane < nc) ? dodv : 0.0;
-                v = is_rhs ? 1.0 : v;
-                a[DROW0 + d] = d < D ? v : 0.0;
+                for (int r = 0; r < NP; ++r) Rm[r * RP + lane] = top[r];
+#pragma unroll
+                for (int r = NP; r < NP + Dm::PAD; ++r) Rm[r * RP + lane] = 0.0;
             }
         }
-        wave_lds_sync();          // the staging area is R's from here on
+        wave_lds_sync();
 
-        double dd;                 // dots of the pivot column with every column (lane = column)
-        {
-            double acc0 = 0.0, acc1 = 0.0;
+        double dd = 0.0;           // dots of the pivot column with every column (lane = column)
+        if (lane < RP) {           // (the other lanes sit the factorisation out)
+            double *const Rl = Rm + lane;
+            {
+                double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-            for (int r = 0; r < ROWS; r += 2) {
-                const double x0 = rl64(a[r], 0), x1 = rl64(a[r + 1], 0);
-                acc0 = fma(x0, a[r], acc0);
-                acc1 = fma(x1, a[r + 1], acc1);
-            }
-            dd = acc0 + acc1;
-        }
-        for (int t = 0; t < nc; ++t) {
-            double rowk = 0.0;
-            switch (t) {
-                NIN_MFW_CASES12(0) NIN_MFW_CASES12(12) NIN_MFW_CASES12(24)
-                default: break;
-            }
-            const double dk = rl64(dd, t), alpha = rl64(rowk, t);
-            const double sq = dk * fast_rsqrt(dk);                   // |(alpha, x)|
-            const double beta = -copysign(sq, alpha);
-            const double inv = fast_rcp(fma(fabs(alpha), sq, dk));   // 1 / (beta (beta - alpha))
-            const double vk = alpha - beta;
-            const double w = lane > t ? (dd - beta * rowk) * inv : 0.0;
-            double rrow = fma(-vk, w, rowk);                          // row t of R
-            rrow = lane == t ? beta : rrow;
-            rrow = lane < t ? 0.0 : rrow;
-            if (lane < RP) Rm[t * RP + lane] = rrow;
-            double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-            for (int b = 0; b < ROWS / 8; ++b) {
-                if (8 * b + 7 <= t) continue;                        // (wave-uniform) these 8 rows have all retired
-                double x[8], xn[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) x[q] = rl64(a[8 * b + q], t);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) a[8 * b + q] = fma(-x[q], w, a[8 * b + q]);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) xn[q] = rl64(a[8 * b + q], t + 1);
-#pragma unroll
-                for (int q = 0; q < 8; q += 2) {
-                    acc0 = fma(xn[q], a[8 * b + q], acc0);
-                    acc1 = fma(xn[q + 1], a[8 * b + q + 1], acc1);
+                for (int r = 0; r < NP; r += 2) {
+                    const double v0 = Rl[r * RP], v1 = Rl[(r + 1) * RP];
+                    acc0 = fma(rl64(v0, 0), v0, acc0);
+                    acc1 = fma(rl64(v1, 0), v1, acc1);
                 }
+#pragma unroll
+                for (int r = 0; r + 1 < NREG; r += 2) {
+                    acc0 = fma(rl64(a[r], 0), a[r], acc0);
+                    acc1 = fma(rl64(a[r + 1], 0), a[r + 1], acc1);
+                }
+                if (NREG & 1) acc0 = fma(rl64(a[NREG - 1], 0), a[NREG - 1], acc0);
+                dd = acc0 + acc1;
             }
-            dd = acc0 + acc1;
+            for (int t = 0; t < nc; ++t) {
+                const double rowk = Rl[t * RP];
+                // the rows still waiting in LDS, t + 1 .. NP - 1, in groups of G (the zero rows behind them fill the last
+                // group); the first group's loads overlap the scalar chain below
+                constexpr int G = 4;
+                double *lp = Rl + (t + 1) * RP;
+                const int groups = (NP - 1 - t + G - 1) / G;
+                double cur[G];
+#pragma unroll
+                for (int q = 0; q < G; ++q) cur[q] = lp[q * RP];
+                const double dk = rl64(dd, t), alpha = rl64(rowk, t);
+                const double sq = dk * fast_rsqrt(dk);                   // |(alpha, x)|
+                const double beta = -copysign(sq, alpha);
+                const double inv = fast_rcp(fma(fabs(alpha), sq, dk));   // 1 / (beta (beta - alpha))
+                const double vk = alpha - beta;
+                const double w = lane > t ? (dd - beta * rowk) * inv : 0.0;
+                double rrow = fma(-vk, w, rowk);                          // row t of R, in place of the pivot row
+                rrow = lane == t ? beta : rrow;
+                rrow = lane < t ? 0.0 : rrow;
+                Rl[t * RP] = rrow;
+                double acc0 = 0.0, acc1 = 0.0;
+                for (int gi = 0; gi < groups; ++gi) {
+                    double nx[G], x[G], xn[G];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) nx[q] = lp[(G + q) * RP];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) x[q] = rl64(cur[q], t);
+#pragma unroll
+                    for (int q = 0; q < G; ++q) cur[q] = fma(-x[q], w, cur[q]);
+#pragma unroll
+                    for (int q = 0; q < G; ++q) lp[q * RP] = cur[q];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) xn[q] = rl64(cur[q], t + 1);
+#pragma unroll
+                    for (int q = 0; q < G; q += 2) {
+                        acc0 = fma(xn[q], cur[q], acc0);
+                        acc1 = fma(xn[q + 1], cur[q + 1], acc1);
+                    }
+#pragma unroll
+                    for (int q = 0; q < G; ++q) cur[q] = nx[q];
+                    lp += G * RP;
+                }
+                constexpr int B = 6;
+                static_assert(NREG % B == 0, "register rows come in blocks");
+#pragma unroll
+                for (int b = 0; b < NREG / B; ++b) {
+                    double x[B], xn[B];
+#pragma unroll
+                    for (int q = 0; q < B; ++q) x[q] = rl64(a[B * b + q], t);
+#pragma unroll
+                    for (int q = 0; q < B; ++q) a[B * b + q] = fma(-x[q], w, a[B * b + q]);
+#pragma unroll
+                    for (int q = 0; q < B; ++q) xn[q] = rl64(a[B * b + q], t + 1);
+#pragma unroll
+                    for (int q = 0; q < B; q += 2) {
+                        acc0 = fma(xn[q], a[B * b + q], acc0);
+                        acc1 = fma(xn[q + 1], a[B * b + q + 1], acc1);
+                    }
+                }
+                dd = acc0 + acc1;
+            }
         }
         const double rr = rl64(dd, nc);                               // r . r = |(Q^T c)(nc:)|^2
         wave_lds_sync();
@@ -364,14 +412,18 @@ int launch_mfw_desc(const GridView &g, const int32_t *nodes, int32_t count, uint
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int add_neumann,
+int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int small, int add_neumann,
                    double *out, double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
     int64_t blocks = ((int64_t)count + 3) / 4;
     const int64_t cap = 2 * 256;   // <= 256 registers per lane: two 4-wave workgroups per CU are resident; persistent
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(nin_gls_mfw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count, add_neumann,
-                       out, nws, queue);
+    if (small)
+        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwSmallFronts, kMfwSmallDense>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                           g, nodes, desc, count, add_neumann, out, nws, queue);
+    else
+        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwMaxFronts, kMfwMaxDense>), dim3((unsigned)blocks), dim3(256), 0, stream, g,
+                           nodes, desc, count, add_neumann, out, nws, queue);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

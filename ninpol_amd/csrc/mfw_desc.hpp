@@ -27,6 +27,7 @@
 namespace nin {
 
 constexpr int kMfwMaxFronts = 12, kMfwMaxDense = 12, kMfwDescWords = 32;
+constexpr int kMfwSmallFronts = 6, kMfwSmallDense = 6;   // the kernel's second instantiation (wedge nodes: 6 + 6, cube nodes: 4 + 4)
 
 #ifdef __HIPCC__
 __device__ inline bool mfw_descriptor(const GridView &g, int32_t p, uint32_t w[kMfwDescWords]) {
