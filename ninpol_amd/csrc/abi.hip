@@ -714,4 +714,14 @@ const char *nin_kernel_name(int method) {
     return kernel_name_gls_hex8mf();   // dominant on hexahedron meshes; kernel_name_gls_block() covers the other nodes
 }
 
+int nin_gls_plan(const nin_grid *g, int64_t counts[8]) {
+    if (!g || !counts) return fail(NIN_EINVAL, "NULL argument");
+    if (g->d.device < 0 || g->d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
+    for (int c = 0; c < kGlsClasses; ++c) counts[c] = g->d.gls[c].count;
+    counts[5] = g->d.hex8.count;
+    counts[6] = g->d.mfw[0].count;
+    counts[7] = g->d.mfw[1].count;
+    return NIN_OK;
+}
+
 }  // extern "C"

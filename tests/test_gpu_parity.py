@@ -169,19 +169,56 @@ def test_gpu_gls_global_scratch_path(oracle_lib, monkeypatch):
     assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
 
 
-def test_gpu_generic_kernel_on_hex(oracle_lib, monkeypatch):
-    """The general one-node-per-wavefront kernel on hexahedron interior nodes (group kernel switched off)."""
+@pytest.mark.parametrize("no_mfw", [True, False])
+def test_gpu_generic_kernel_on_hex(oracle_lib, monkeypatch, no_mfw):
+    """Hexahedron interior nodes with the cube-node kernel switched off: through the block kernel (both special kernels
+    off), and through the small instantiation of the one-wavefront multifrontal kernel (4 fronts + 4 dense cells)."""
     monkeypatch.setenv("NIN_GLS_NO_GROUP", "1")
+    if no_mfw:
+        monkeypatch.setenv("NIN_GLS_NO_MFW", "1")
     mesh = M.hex_mesh(9, jitter=0.15, seed=5)
     M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(0, 1.0), seed=2)
     o = oracle_lib.OracleInterpolator("port", threads=2)
     o.load_mesh(mesh)
     I = _interp()
     I.load_mesh(mesh_obj=mesh)
+    I.grid.to_device(0)
+    plan = I.grid.gls_plan()
+    assert plan["hex8"] == 0 and plan["mfw_large"] == 0
+    assert plan["mfw_small"] == (0 if no_mfw else 8 ** 3)
     wo, no = o.prepare("gls", "u")
     w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
     assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL
     assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
+
+
+@pytest.mark.parametrize("kind", ["tet", "wedge", "mixed"])
+def test_gpu_block_kernel_where_mfw_would_run(oracle_lib, monkeypatch, kind):
+    """Interior nodes of tetrahedron / wedge / mixed meshes go to the one-wavefront multifrontal kernel by default; with
+    it switched off they take the block kernel (sparse first phase, 2 and 4 wavefronts per node), which still serves every
+    node the multifrontal kernels refuse (boundary faces, odd cycles in the cell graph, pyramid apexes) -- and the plan
+    says which kernel ran."""
+    mesh = {"tet": lambda: M.tet_mesh(5, jitter=0.1, seed=3), "wedge": lambda: M.wedge_mesh(5, jitter=0.05, seed=3),
+            "mixed": lambda: M.mixed_mesh(8, 4, 4, jitter=0.1, seed=3)}[kind]()
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=4)
+    o = oracle_lib.OracleInterpolator("port", threads=4)
+    o.load_mesh(mesh)
+    wo, no = o.prepare("gls", "u")
+    plans = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("NIN_GLS_NO_MFW", "1")
+        I = _interp()
+        I.load_mesh(mesh_obj=mesh)
+        I.grid.to_device(0)
+        plans[off] = I.grid.gls_plan()
+        w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+        assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL, off
+        assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL, off
+    assert plans[True]["mfw_large"] == 0 and plans[True]["mfw_small"] == 0
+    taken = plans[False]["mfw_large"] + plans[False]["mfw_small"]
+    assert taken == {"tet": 4 ** 3, "wedge": 4 ** 3}.get(kind, taken) and taken > 0
+    assert sum(plans[False].values()) == sum(plans[True].values()) == I.grid.n_points
 
 
 @pytest.mark.parametrize("sectors,layers", [(15, 3), (30, 3), (50, 2), (80, 2)])
