@@ -58,7 +58,120 @@ __device__ __forceinline__ double rl64(double v, int lane) {
 }
 __device__ __forceinline__ uint32_t rl32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
-template <int FM, int DM>
+// ---- the dense problem with lane = ROW (large instantiation) -------------------------------------------------------------
+// Cross-lane pieces.  v_permlane32_swap / v_permlane16_swap (gfx950) exchange halves / odd-even 16-lane rows between
+// TWO registers: one instruction per dword moves two columns' partial sums towards each other.
+__device__ __forceinline__ void swap32(double &x, double &y) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap16(double &x, double &y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// sum over the 16 lanes of a row, in every lane of the row
+__device__ __forceinline__ double row_allsum(double v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    return v;
+}
+// sum over the 64 lanes, in every lane
+__device__ __forceinline__ double wave_allsum(double v) {
+    v = row_allsum(v);
+    double x = v, y = v;
+    swap16(x, y);             // x = [r0 r0 r2 r2], y = [r1 r1 r3 r3]
+    v = x + y;
+    x = v; y = v;
+    swap32(x, y);             // x = [lo lo], y = [hi hi]
+    return x + y;
+}
+// Four columns' per-lane partial sums -> one register whose 16-lane rows hold the four totals:
+// row 0: p0, row 1: p2, row 2: p1, row 3: p3 (every lane of the row).
+__device__ __forceinline__ double reduce4(double p0, double p1, double p2, double p3) {
+    swap32(p0, p1);           // p0 = [p0.lo | p1.lo], p1 = [p0.hi | p1.hi]
+    const double s01 = p0 + p1;
+    swap32(p2, p3);
+    const double s23 = p2 + p3;
+    double x = s01, y = s23;
+    swap16(x, y);             // x = [s01.r0, s23.r0, s01.r2, s23.r2], y = [s01.r1, s23.r1, s01.r3, s23.r3]
+    return row_allsum(x + y);
+}
+constexpr int kReduce4Lane[4] = {0, 32, 16, 48};   // where column i of a reduce4 group is read back
+
+// One Householder step with the rows in the lanes: lane r holds row 36 + r of the dense problem in a[] (r < 60) and,
+// r < 36, pivot row r in b[]; registers S .. C - 1 of a[] / b[] are the live columns (S the pivot column), ca / cb the
+// right-hand side c.  The reflector is v = (the pivot column's entries; alpha - beta in the pivot row's lane), so one
+// reduction per column gives w_j = g (v . C_j) directly, w_j goes to a scalar register pair and every row's update is one
+// FMA per array: two v_readlane per COLUMN and step instead of four per ROW and step.  Row t of R leaves through LDS.
+template <int C, int S>
+__device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], double &ca, double &cb, int t, int col0, int nc,
+                                          int lane, double *Rm, int RP) {
+    const bool live_b = lane > t, piv = lane == t;
+    const double xa = a[S], xb0 = lane >= t ? b[S] : 0.0;
+    const double dk = wave_allsum(fma(xa, xa, xb0 * xb0));          // |(alpha, x)|^2
+    const double alpha = rl64(b[S], t);
+    const double sq = dk * fast_rsqrt(dk);
+    const double beta = -copysign(sq, alpha);
+    const double inv = fast_rcp(fma(fabs(alpha), sq, dk));           // g = 1 / (beta (beta - alpha))
+    const double vk = alpha - beta;
+    const double xb = piv ? vk : (live_b ? b[S] : 0.0);
+    double *const Rt = Rm + t * RP;                                  // row t of R (the pivot lane writes it)
+    if (piv) Rt[t] = beta;
+    constexpr int NL = C - 1 - S;                                    // live columns behind the pivot, then c
+#pragma unroll
+    for (int i0 = 0; i0 < NL + 1; i0 += 4) {
+        double p[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            if (i < NL) p[q] = fma(xb, b[S + 1 + i], xa * a[S + 1 + i]);
+            else if (i == NL) p[q] = fma(xb, cb, xa * ca);
+            else p[q] = 0.0;
+        }
+        const double wu = reduce4(p[0], p[1], p[2], p[3]) * inv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            if (i > NL) continue;
+            const double wj = rl64(wu, kReduce4Lane[q]);
+            if (i < NL) {
+                a[S + 1 + i] = fma(-xa, wj, a[S + 1 + i]);
+                b[S + 1 + i] = fma(-xb, wj, b[S + 1 + i]);
+            } else {
+                ca = fma(-xa, wj, ca);
+                cb = fma(-xb, wj, cb);
+            }
+        }
+        if (piv) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q;
+                if (i < NL) Rt[col0 + S + 1 + i] = b[S + 1 + i];
+                else if (i == NL) Rt[nc] = cb;
+            }
+        }
+    }
+}
+// three steps (one dense cell's columns), then the columns move down by three
+template <int C>
+__device__ __forceinline__ void rows_block(double (&a)[36], double (&b)[36], double &ca, double &cb, int k, int nc, int lane,
+                                           double *Rm, int RP) {
+    rows_step<C, 0>(a, b, ca, cb, 3 * k + 0, 3 * k, nc, lane, Rm, RP);
+    rows_step<C, 1>(a, b, ca, cb, 3 * k + 1, 3 * k, nc, lane, Rm, RP);
+    rows_step<C, 2>(a, b, ca, cb, 3 * k + 2, 3 * k, nc, lane, Rm, RP);
+#pragma unroll
+    for (int i = 0; i + 3 < C; ++i) { a[i] = a[i + 3]; b[i] = b[i + 3]; }
+#pragma unroll
+    for (int i = C - 3; i < C; ++i) { a[i] = 0.0; b[i] = 0.0; }
+}
+
+template <int FM, int DM, bool ROWS_IN_LANES>
 __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                               const uint32_t *__restrict__ desc, int32_t count,
                                                               int add_neumann, double *__restrict__ out,
@@ -216,9 +329,52 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         if (lane < D) { dbuf[3 * lane + 0] = dod[0]; dbuf[3 * lane + 1] = dod[1]; dbuf[3 * lane + 2] = dod[2]; }
         wave_lds_sync();
 
+        const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
+        double rr;
+        if constexpr (ROWS_IN_LANES) {
+            // ---- the dense problem, lane = ROW: lane r holds row NP + r (r < NREG) in a[], pivot row r (r < NP) in b[] -------
+            static_assert(!ROWS_IN_LANES || (NP == 36 && NREG <= 64), "one row per lane and array");
+            double a[36], b[36], ca, cb;
+            {
+                const uint32_t w0all = w0, w1all = w1;
+                auto gather = [&](int row, bool have, double (&x)[36], double &xc) {
+                    const bool fill = row < 7 * FM;
+                    const int f = fill ? (row * 37) >> 8 : 0, i = row - 7 * f, d = row - 7 * FM;
+                    const uint32_t q0 = (uint32_t)__shfl((int)w0all, f), q1 = (uint32_t)__shfl((int)w1all, f);
+                    const int s0 = (q0 >> 11) & 15, s1 = (q1 >> 6) & 15, s2 = (q1 >> 22) & 15;   // dense slots of the front's 3 neighbours
+                    const bool ok = have && (fill ? f < F : d < D);
+                    const int fbase = f * STAGE_F + i * 10;
+#pragma unroll
+                    for (int sj = 0; sj < DM; ++sj) {
+                        int off = Dm::LDS_Z;                                  // zeros
+                        if (fill) {
+                            off = s0 == sj ? fbase : off;
+                            off = s1 == sj ? fbase + 3 : off;
+                            off = s2 == sj ? fbase + 6 : off;
+                        } else {
+                            off = d == sj ? Dm::LDS_D + 3 * sj : off;        // the cell row of dense cell d: (x_K - x_v) on its own columns
+                        }
+                        off = ok ? off : Dm::LDS_Z;
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt) x[3 * sj + tt] = Rm[off + tt];
+                    }
+                    xc = ok ? (fill ? Rm[fbase + 9] : 1.0) : 0.0;
+                };
+                gather(NP + lane, lane < NREG, a, ca);
+                gather(lane < NP ? lane : 0, lane < NP, b, cb);
+            }
+            wave_lds_sync();          // the staging area is R's from here on
+            for (int k = 0; k < D; ++k) {
+                if (k < 3) rows_block<36>(a, b, ca, cb, k, nc, lane, Rm, RP);
+                else if (k < 6) rows_block<27>(a, b, ca, cb, k, nc, lane, Rm, RP);
+                else if (k < 9) rows_block<18>(a, b, ca, cb, k, nc, lane, Rm, RP);
+                else rows_block<9>(a, b, ca, cb, k, nc, lane, Rm, RP);
+            }
+            const double cbl = lane >= nc ? cb : 0.0;                // pivot rows that never got their turn (D < DM) count too
+            rr = wave_allsum(fma(ca, ca, cbl * cbl));                // r . r = |(Q^T c)(nc:)|^2
+        } else {
         // ---- the dense problem, lane = column: rows 0 .. NP-1 (fill rows of the first fronts) go to LDS, the others
         //      stay in the register pairs a[] ---------------------------------------------------------------------------------
-        const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
         const bool is_rhs = lane == nc;
         double a[NREG];
         {
@@ -341,7 +497,8 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
                 dd = acc0 + acc1;
             }
         }
-        const double rr = rl64(dd, nc);                               // r . r = |(Q^T c)(nc:)|^2
+        rr = rl64(dd, nc);                                            // r . r = |(Q^T c)(nc:)|^2
+        }
         wave_lds_sync();
 
         // ---- R y = (Q^T c)(0:nc) by columns: lane = row ------------------------------------------------------------------
@@ -418,12 +575,16 @@ int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc
     int64_t blocks = ((int64_t)count + 3) / 4;
     const int64_t cap = 2 * 256;   // <= 256 registers per lane: two 4-wave workgroups per CU are resident; persistent
     if (blocks > cap) blocks = cap;
+    static const bool lane_columns = getenv("NIN_MFW_LANE_COLUMNS") != nullptr;   // A/B switch: the large instantiation's first form
     if (small)
-        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwSmallFronts, kMfwSmallDense>), dim3((unsigned)blocks), dim3(256), 0, stream,
+        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwSmallFronts, kMfwSmallDense, false>), dim3((unsigned)blocks), dim3(256), 0,
+                           stream, g, nodes, desc, count, add_neumann, out, nws, queue);
+    else if (lane_columns)
+        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwMaxFronts, kMfwMaxDense, false>), dim3((unsigned)blocks), dim3(256), 0, stream,
                            g, nodes, desc, count, add_neumann, out, nws, queue);
     else
-        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwMaxFronts, kMfwMaxDense>), dim3((unsigned)blocks), dim3(256), 0, stream, g,
-                           nodes, desc, count, add_neumann, out, nws, queue);
+        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwMaxFronts, kMfwMaxDense, true>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                           g, nodes, desc, count, add_neumann, out, nws, queue);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
