@@ -37,6 +37,10 @@ namespace {
 
 using namespace glsmath;
 
+#ifndef NIN_MFW_BODIES
+#define NIN_MFW_BODIES 3
+#endif
+
 constexpr int STAGE_F = 70;   // per front: 7 fill rows x (9 neighbour columns + c)
 
 // Sizes for nodes with at most FM fronts and DM dense cells: 7 FM + DM dense rows -- the first NP = 3 DM of them (the
@@ -365,10 +369,21 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
             }
             wave_lds_sync();          // the staging area is R's from here on
             for (int k = 0; k < D; ++k) {
+                // (a body for C live columns serves several cells' blocks, the columns beyond the live ones being zero: more
+                //  bodies pad less but the code outgrows the instruction cache: tet40 with 2 / 3 / 4 / 6 bodies 2.45 / 2.41 / 2.72 / 3.47 ms)
+#if NIN_MFW_BODIES == 2
+                if (k < 6) rows_block<36>(a, b, ca, cb, k, nc, lane, Rm, RP);
+                else rows_block<18>(a, b, ca, cb, k, nc, lane, Rm, RP);
+#elif NIN_MFW_BODIES == 3
+                if (k < 4) rows_block<36>(a, b, ca, cb, k, nc, lane, Rm, RP);
+                else if (k < 8) rows_block<24>(a, b, ca, cb, k, nc, lane, Rm, RP);
+                else rows_block<12>(a, b, ca, cb, k, nc, lane, Rm, RP);
+#else
                 if (k < 3) rows_block<36>(a, b, ca, cb, k, nc, lane, Rm, RP);
                 else if (k < 6) rows_block<27>(a, b, ca, cb, k, nc, lane, Rm, RP);
                 else if (k < 9) rows_block<18>(a, b, ca, cb, k, nc, lane, Rm, RP);
                 else rows_block<9>(a, b, ca, cb, k, nc, lane, Rm, RP);
+#endif
             }
             const double cbl = lane >= nc ? cb : 0.0;                // pivot rows that never got their turn (D < DM) count too
             rr = wave_allsum(fma(ca, ca, cbl * cbl));                // r . r = |(Q^T c)(nc:)|^2
