@@ -378,6 +378,7 @@ def main():
                     row = {"cells": int(Io.grid.n_elems), "nodes": int(Io.grid.n_points)}
                     for meth in meths:
                         row[meth] = timed(Io, meth)
+                    row["gls_nodes_per_kernel"] = {k: v for k, v in Io.grid.gls_plan().items() if v}
                     rows[name] = row
                     del Io, mo
                     torch.cuda.empty_cache()

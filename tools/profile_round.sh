@@ -18,6 +18,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
 done
 # the block kernel by size class on the mixed and Kuhn-tet meshes (BASELINE config [3] at size: mixed10m)
 NIN_GRID_BUILD=device timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mixed_tet -- python3 tools/time_methods.py mixed tet40 wedge60 mixed10m > $OUT/methods_by_mesh.txt 2> $OUT/mixed_tet.err || { echo "mixed/tet pass failed"; tail -5 $OUT/mixed_tet.err; }
+# issue-side counters of the one-wavefront multifrontal kernel on the Kuhn-tet mesh (the instruction cache matters there)
+NIN_METHODS=gls timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IFETCH --output-format csv -d $OUT/pmc_tet -- python3 tools/time_methods.py tet40 > $OUT/pmc_tet.txt 2> $OUT/pmc_tet.err || { echo "tet pmc pass failed"; tail -5 $OUT/pmc_tet.err; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, json, collections, os
 out = sys.argv[1]
