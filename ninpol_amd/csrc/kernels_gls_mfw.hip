@@ -37,10 +37,6 @@ namespace {
 
 using namespace glsmath;
 
-#ifndef NIN_MFW_BODIES
-#define NIN_MFW_BODIES 3
-#endif
-
 constexpr int STAGE_F = 70;   // per front: 7 fill rows x (9 neighbour columns + c)
 
 // Sizes for nodes with at most FM fronts and DM dense cells: 7 FM + DM dense rows -- the first NP = 3 DM of them (the
@@ -109,13 +105,15 @@ __device__ __forceinline__ double reduce4(double p0, double p1, double p2, doubl
 constexpr int kReduce4Lane[4] = {0, 32, 16, 48};   // where column i of a reduce4 group is read back
 
 // One Householder step with the rows in the lanes: lane r holds row 36 + r of the dense problem in a[] (r < 60) and,
-// r < 36, pivot row r in b[]; registers S .. C - 1 of a[] / b[] are the live columns (S the pivot column), ca / cb the
-// right-hand side c.  The reflector is v = (the pivot column's entries; alpha - beta in the pivot row's lane), so one
-// reduction per column gives w_j = g (v . C_j) directly, w_j goes to a scalar register pair and every row's update is one
-// FMA per array: two v_readlane per COLUMN and step instead of four per ROW and step.  Row t of R leaves through LDS.
-template <int C, int S>
-__device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], double &ca, double &cb, int t, int col0, int nc,
-                                          int lane, double *Rm, int RP) {
+// r < 36, pivot row r in b[]; registers S .. live - 1 of a[] / b[] are the live columns (S the pivot column; the
+// registers from `live` on are zero), ca / cb the right-hand side c.  The reflector is v = (the pivot column's entries;
+// alpha - beta in the pivot row's lane), so one reduction per column gives w_j = g (v . C_j) directly, w_j goes to a
+// scalar register pair and every row's update is one FMA per array: two v_readlane per COLUMN and step instead of four
+// per ROW and step.  Columns go four at a time (c rides with the first three); groups that lie in the zero registers
+// altogether are skipped (wave-uniform), so ONE body serves every cell.  Row t of R leaves through LDS.
+template <int S>
+__device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], double &ca, double &cb, int t, int col0, int live,
+                                          int nc, int lane, double *Rm, int RP) {
     const bool live_b = lane > t, piv = lane == t;
     const double xa = a[S], xb0 = lane >= t ? b[S] : 0.0;
     const double dk = wave_allsum(fma(xa, xa, xb0 * xb0));          // |(alpha, x)|^2
@@ -127,52 +125,59 @@ __device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], doub
     const double xb = piv ? vk : (live_b ? b[S] : 0.0);
     double *const Rt = Rm + t * RP;                                  // row t of R (the pivot lane writes it)
     if (piv) Rt[t] = beta;
-    constexpr int NL = C - 1 - S;                                    // live columns behind the pivot, then c
+    // group 0: c and the registers S + 1 .. S + 3; group m: the registers S + 4 m .. S + 4 m + 3
+    constexpr int NG = (36 - S + 3) / 4;
 #pragma unroll
-    for (int i0 = 0; i0 < NL + 1; i0 += 4) {
+    for (int m = 0; m < NG; ++m) {
+        if (m > 0 && S + 4 * m >= live) continue;                    // (wave-uniform) nothing but zeros in this group
         double p[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q;
-            if (i < NL) p[q] = fma(xb, b[S + 1 + i], xa * a[S + 1 + i]);
-            else if (i == NL) p[q] = fma(xb, cb, xa * ca);
+            const int r = S + 4 * m + q;                             // register; r == S stands for c
+            if (r == S) p[q] = fma(xb, cb, xa * ca);
+            else if (r < 36) p[q] = fma(xb, b[r], xa * a[r]);
             else p[q] = 0.0;
         }
         const double wu = reduce4(p[0], p[1], p[2], p[3]) * inv;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q;
-            if (i > NL) continue;
+            const int r = S + 4 * m + q;
+            if (r >= 36) continue;
             const double wj = rl64(wu, kReduce4Lane[q]);
-            if (i < NL) {
-                a[S + 1 + i] = fma(-xa, wj, a[S + 1 + i]);
-                b[S + 1 + i] = fma(-xb, wj, b[S + 1 + i]);
-            } else {
+            if (r == S) {
                 ca = fma(-xa, wj, ca);
                 cb = fma(-xb, wj, cb);
+            } else {
+                a[r] = fma(-xa, wj, a[r]);
+                b[r] = fma(-xb, wj, b[r]);
             }
         }
         if (piv) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = i0 + q;
-                if (i < NL) Rt[col0 + S + 1 + i] = b[S + 1 + i];
-                else if (i == NL) Rt[nc] = cb;
+                const int r = S + 4 * m + q;
+                if (r != S && r < 36) Rt[col0 + r] = b[r];
             }
         }
     }
+    if (piv) Rt[nc] = cb;            // (last: a zero register of the last group may sit on column nc)
 }
 // three steps (one dense cell's columns), then the columns move down by three
-template <int C>
 __device__ __forceinline__ void rows_block(double (&a)[36], double (&b)[36], double &ca, double &cb, int k, int nc, int lane,
                                            double *Rm, int RP) {
-    rows_step<C, 0>(a, b, ca, cb, 3 * k + 0, 3 * k, nc, lane, Rm, RP);
-    rows_step<C, 1>(a, b, ca, cb, 3 * k + 1, 3 * k, nc, lane, Rm, RP);
-    rows_step<C, 2>(a, b, ca, cb, 3 * k + 2, 3 * k, nc, lane, Rm, RP);
+    const int live = nc - 3 * k;
+    rows_step<0>(a, b, ca, cb, 3 * k + 0, 3 * k, live, nc, lane, Rm, RP);
+    rows_step<1>(a, b, ca, cb, 3 * k + 1, 3 * k, live, nc, lane, Rm, RP);
+    rows_step<2>(a, b, ca, cb, 3 * k + 2, 3 * k, live, nc, lane, Rm, RP);
 #pragma unroll
-    for (int i = 0; i + 3 < C; ++i) { a[i] = a[i + 3]; b[i] = b[i + 3]; }
+    for (int i0 = 0; i0 < 36; i0 += 3) {
+        if (i0 >= live) continue;                                    // (zeros would move onto zeros)
 #pragma unroll
-    for (int i = C - 3; i < C; ++i) { a[i] = 0.0; b[i] = 0.0; }
+        for (int i = i0; i < i0 + 3; ++i) {
+            a[i] = i + 3 < 36 ? a[i + 3] : 0.0;
+            b[i] = i + 3 < 36 ? b[i + 3] : 0.0;
+        }
+    }
 }
 
 template <int FM, int DM, bool ROWS_IN_LANES>
@@ -369,21 +374,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
             }
             wave_lds_sync();          // the staging area is R's from here on
             for (int k = 0; k < D; ++k) {
-                // (a body for C live columns serves several cells' blocks, the columns beyond the live ones being zero: more
-                //  bodies pad less but the code outgrows the instruction cache: tet40 with 2 / 3 / 4 / 6 bodies 2.45 / 2.41 / 2.72 / 3.47 ms)
-#if NIN_MFW_BODIES == 2
-                if (k < 6) rows_block<36>(a, b, ca, cb, k, nc, lane, Rm, RP);
-                else rows_block<18>(a, b, ca, cb, k, nc, lane, Rm, RP);
-#elif NIN_MFW_BODIES == 3
-                if (k < 4) rows_block<36>(a, b, ca, cb, k, nc, lane, Rm, RP);
-                else if (k < 8) rows_block<24>(a, b, ca, cb, k, nc, lane, Rm, RP);
-                else rows_block<12>(a, b, ca, cb, k, nc, lane, Rm, RP);
-#else
-                if (k < 3) rows_block<36>(a, b, ca, cb, k, nc, lane, Rm, RP);
-                else if (k < 6) rows_block<27>(a, b, ca, cb, k, nc, lane, Rm, RP);
-                else if (k < 9) rows_block<18>(a, b, ca, cb, k, nc, lane, Rm, RP);
-                else rows_block<9>(a, b, ca, cb, k, nc, lane, Rm, RP);
-#endif
+                rows_block(a, b, ca, cb, k, nc, lane, Rm, RP);
             }
             const double cbl = lane >= nc ? cb : 0.0;                // pivot rows that never got their turn (D < DM) count too
             rr = wave_allsum(fma(ca, ca, cbl * cbl));                // r . r = |(Q^T c)(nc:)|^2
