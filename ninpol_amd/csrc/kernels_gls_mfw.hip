@@ -110,10 +110,9 @@ constexpr int kReduce4Lane[4] = {0, 32, 16, 48};   // where column i of a reduce
 // alpha - beta in the pivot row's lane), so one reduction per column gives w_j = g (v . C_j) directly, w_j goes to a
 // scalar register pair and every row's update is one FMA per array: two v_readlane per COLUMN and step instead of four
 // per ROW and step.  Columns go four at a time (c rides with the first three); groups that lie in the zero registers
-// altogether are skipped (wave-uniform), so ONE body serves every cell.  Row t of R leaves through LDS.
+// altogether are skipped (wave-uniform), so ONE body serves every cell.
 template <int S>
-__device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], double &ca, double &cb, int t, int col0, int live,
-                                          int nc, int lane, double *Rm, int RP) {
+__device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], double &ca, double &cb, int t, int live, int lane) {
     const bool live_b = lane > t, piv = lane == t;
     const double xa = a[S], xb0 = lane >= t ? b[S] : 0.0;
     const double dk = wave_allsum(fma(xa, xa, xb0 * xb0));          // |(alpha, x)|^2
@@ -123,8 +122,7 @@ __device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], doub
     const double inv = fast_rcp(fma(fabs(alpha), sq, dk));           // g = 1 / (beta (beta - alpha))
     const double vk = alpha - beta;
     const double xb = piv ? vk : (live_b ? b[S] : 0.0);
-    double *const Rt = Rm + t * RP;                                  // row t of R (the pivot lane writes it)
-    if (piv) Rt[t] = beta;
+    b[S] = piv ? beta : b[S];                                        // R(t, t); the rest of row t of R takes shape in the pivot lane's b[]
     // group 0: c and the registers S + 1 .. S + 3; group m: the registers S + 4 m .. S + 4 m + 3
     constexpr int NG = (36 - S + 3) / 4;
 #pragma unroll
@@ -152,23 +150,21 @@ __device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], doub
                 b[r] = fma(-xb, wj, b[r]);
             }
         }
-        if (piv) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = S + 4 * m + q;
-                if (r != S && r < 36) Rt[col0 + r] = b[r];
-            }
-        }
     }
-    if (piv) Rt[nc] = cb;            // (last: a zero register of the last group may sit on column nc)
 }
 // three steps (one dense cell's columns), then the columns move down by three
 __device__ __forceinline__ void rows_block(double (&a)[36], double (&b)[36], double &ca, double &cb, int k, int nc, int lane,
                                            double *Rm, int RP) {
     const int live = nc - 3 * k;
-    rows_step<0>(a, b, ca, cb, 3 * k + 0, 3 * k, live, nc, lane, Rm, RP);
-    rows_step<1>(a, b, ca, cb, 3 * k + 1, 3 * k, live, nc, lane, Rm, RP);
-    rows_step<2>(a, b, ca, cb, 3 * k + 2, 3 * k, live, nc, lane, Rm, RP);
+    rows_step<0>(a, b, ca, cb, 3 * k + 0, live, lane);
+    rows_step<1>(a, b, ca, cb, 3 * k + 1, live, lane);
+    rows_step<2>(a, b, ca, cb, 3 * k + 2, live, lane);
+    // A retired pivot row is never touched again (its entry of every later reflector is zero), so row t of R simply
+    // stays in lane t's b[] -- until the columns move down.  The three that are about to leave, R(0 .. 3k+2, 3k .. 3k+2):
+    if (lane < 3 * k + 3) {
+        double *Rt = Rm + lane * RP + 3 * k;
+        Rt[0] = b[0]; Rt[1] = b[1]; Rt[2] = b[2];
+    }
 #pragma unroll
     for (int i0 = 0; i0 < 36; i0 += 3) {
         if (i0 >= live) continue;                                    // (zeros would move onto zeros)
@@ -376,6 +372,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
             for (int k = 0; k < D; ++k) {
                 rows_block(a, b, ca, cb, k, nc, lane, Rm, RP);
             }
+            if (lane < nc) Rm[lane * RP + nc] = cb;                  // (Q^T c)(0:nc), the last column of R
             const double cbl = lane >= nc ? cb : 0.0;                // pivot rows that never got their turn (D < DM) count too
             rr = wave_allsum(fma(ca, ca, cbl * cbl));                // r . r = |(Q^T c)(nc:)|^2
         } else {
