@@ -111,38 +111,44 @@ constexpr int kReduce4Lane[4] = {0, 32, 16, 48};   // where column i of a reduce
 // scalar register pair and every row's update is one FMA per array: two v_readlane per COLUMN and step instead of four
 // per ROW and step.  Columns go four at a time (c rides with the first three); groups that lie in the zero registers
 // altogether are skipped (wave-uniform), so ONE body serves every cell.
+// the register behind slot q of column group m of step S: -1 = the right-hand side c, -2 = the squared norm of the NEXT
+// pivot column (it rides along, so only a node's first step needs a reduction of its own), >= 36 = empty
+__device__ constexpr int slot_reg(int S, int m, int q) {
+    return m == 0 ? (q == 0 ? -1 : S + q) : m == 1 ? (q == 0 ? -2 : S + 3 + q) : S + 4 * m - 1 + q;
+}
 template <int S>
-__device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], double &ca, double &cb, int t, int live, int lane) {
+__device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], double &ca, double &cb, double &dk, int t, int live,
+                                          int lane) {
     const bool live_b = lane > t, piv = lane == t;
-    const double xa = a[S], xb0 = lane >= t ? b[S] : 0.0;
-    const double dk = wave_allsum(fma(xa, xa, xb0 * xb0));          // |(alpha, x)|^2
+    const double xa = a[S];
     const double alpha = rl64(b[S], t);
-    const double sq = dk * fast_rsqrt(dk);
+    const double sq = dk * fast_rsqrt(dk);                           // dk = |(alpha, x)|^2
     const double beta = -copysign(sq, alpha);
     const double inv = fast_rcp(fma(fabs(alpha), sq, dk));           // g = 1 / (beta (beta - alpha))
     const double vk = alpha - beta;
     const double xb = piv ? vk : (live_b ? b[S] : 0.0);
     b[S] = piv ? beta : b[S];                                        // R(t, t); the rest of row t of R takes shape in the pivot lane's b[]
-    // group 0: c and the registers S + 1 .. S + 3; group m: the registers S + 4 m .. S + 4 m + 3
-    constexpr int NG = (36 - S + 3) / 4;
+    constexpr int NG = (36 - S) / 4 + 1;
 #pragma unroll
     for (int m = 0; m < NG; ++m) {
-        if (m > 0 && S + 4 * m >= live) continue;                    // (wave-uniform) nothing but zeros in this group
+        if (m > 1 && slot_reg(S, m, 0) >= live) continue;            // (wave-uniform) nothing but zeros in this group
         double p[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = S + 4 * m + q;                             // register; r == S stands for c
-            if (r == S) p[q] = fma(xb, cb, xa * ca);
+            const int r = slot_reg(S, m, q);
+            if (r == -1) p[q] = fma(xb, cb, xa * ca);
+            else if (r == -2) { const double bn = live_b ? b[S + 1] : 0.0; p[q] = fma(a[S + 1], a[S + 1], bn * bn); }
             else if (r < 36) p[q] = fma(xb, b[r], xa * a[r]);
             else p[q] = 0.0;
         }
-        const double wu = reduce4(p[0], p[1], p[2], p[3]) * inv;
+        const double tot = reduce4(p[0], p[1], p[2], p[3]), wu = tot * inv;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = S + 4 * m + q;
+            const int r = slot_reg(S, m, q);
             if (r >= 36) continue;
+            if (r == -2) { dk = rl64(tot, kReduce4Lane[q]); continue; }
             const double wj = rl64(wu, kReduce4Lane[q]);
-            if (r == S) {
+            if (r == -1) {
                 ca = fma(-xa, wj, ca);
                 cb = fma(-xb, wj, cb);
             } else {
@@ -153,12 +159,12 @@ __device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], doub
     }
 }
 // three steps (one dense cell's columns), then the columns move down by three
-__device__ __forceinline__ void rows_block(double (&a)[36], double (&b)[36], double &ca, double &cb, int k, int nc, int lane,
-                                           double *Rm, int RP) {
+__device__ __forceinline__ void rows_block(double (&a)[36], double (&b)[36], double &ca, double &cb, double &dk, int k, int nc,
+                                           int lane, double *Rm, int RP) {
     const int live = nc - 3 * k;
-    rows_step<0>(a, b, ca, cb, 3 * k + 0, live, lane);
-    rows_step<1>(a, b, ca, cb, 3 * k + 1, live, lane);
-    rows_step<2>(a, b, ca, cb, 3 * k + 2, live, lane);
+    rows_step<0>(a, b, ca, cb, dk, 3 * k + 0, live, lane);
+    rows_step<1>(a, b, ca, cb, dk, 3 * k + 1, live, lane);
+    rows_step<2>(a, b, ca, cb, dk, 3 * k + 2, live, lane);
     // A retired pivot row is never touched again (its entry of every later reflector is zero), so row t of R simply
     // stays in lane t's b[] -- until the columns move down.  The three that are about to leave, R(0 .. 3k+2, 3k .. 3k+2):
     if (lane < 3 * k + 3) {
@@ -369,8 +375,9 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
                 gather(lane < NP ? lane : 0, lane < NP, b, cb);
             }
             wave_lds_sync();          // the staging area is R's from here on
+            double dk = wave_allsum(fma(a[0], a[0], b[0] * b[0]));    // |column 0|^2; the later ones come out of the steps
             for (int k = 0; k < D; ++k) {
-                rows_block(a, b, ca, cb, k, nc, lane, Rm, RP);
+                rows_block(a, b, ca, cb, dk, k, nc, lane, Rm, RP);
             }
             if (lane < nc) Rm[lane * RP + nc] = cb;                  // (Q^T c)(0:nc), the last column of R
             const double cbl = lane >= nc ? cb : 0.0;                // pivot rows that never got their turn (D < DM) count too
