@@ -11,13 +11,23 @@
 //            quad lanes of the hex8 kernel do it.  Each leaves 3 rows of R, folded at once into what the weights need
 //            of them (z = R_ee^-T d_e, u = z^T R_ed, s = z . b_e), and 7 fill rows over the 9 columns of its three
 //            dense neighbours + c, which go through LDS into
-//   phase 2  the dense (7 F + D) x (3 D + 1) problem -- Kuhn tetrahedra: 96 x 37 -- with lane = COLUMN: a Householder
-//            step broadcasts the pivot column entry of a row with v_readlane, updates the row, and in the same pass
-//            accumulates the next pivot column's dots.  The rows that never become pivot rows (60 of the 96) are
-//            register pairs of the wavefront; the 3 D pivot rows live in LDS, where row t of R replaces pivot row t
-//            in place and only the rows still waiting for their turn are swept.  No barrier, no partial sums, one
-//            wavefront's instruction stream: the block kernel spends 4 wavefronts, an LDS round trip per row and two
-//            workgroup barriers per step on the same sweep, and ~3 x the instructions;
+//   phase 2  the dense (7 F + D) x (3 D + 1) problem -- Kuhn tetrahedra: 96 x 37 -- in one wavefront's registers, no
+//            barrier, no partial sums (the block kernel spends 4 wavefronts, an LDS round trip per row and two workgroup
+//            barriers per step on the same sweep, and ~5 x the instructions).  Two forms:
+//            lane = ROW (large instantiation, up to 12 + 12 cells): lane r holds a non-pivot row in a[36] and, r < 36,
+//              pivot row r in b[36], the columns are static register indices.  With v = the pivot column's entries and
+//              alpha - beta in the pivot lane, ONE reduction per column gives w_j = g (v . C_j), w_j goes to a scalar
+//              register pair and every row's update is one FMA per array.  Four columns are reduced together
+//              (v_permlane32_swap / v_permlane16_swap bring them into the four 16-lane rows of one register, a DPP row
+//              reduction finishes them); the arrays move down by three registers after every cell so that one step body
+//              serves all cells, column groups that hold only zeros being skipped; a retired pivot row keeps row t of
+//              R in its lane's registers, three columns of it are saved to LDS per cell.
+//            lane = COLUMN (small instantiation: wedge 6 + 6 and cube 4 + 4 nodes; the large one's first form, kept
+//              behind NIN_MFW_LANE_COLUMNS): a step broadcasts the pivot column's entry of a row with v_readlane,
+//              updates the row and accumulates the next pivot column's dots in the same pass; the non-pivot rows are
+//              register pairs, the 3 D pivot rows live in LDS where row t of R replaces pivot row t in place.
+//              v_readlane costs ~2 FP64 FMAs of issue time (tools/micro_readlane.hip), 4 of them per row and step:
+//              that is why the rows went into the lanes (tet40: 3.9 -> 2.0 ms);
 //   then     R y = Q^T c by columns (lane = row, R through LDS), r_i = 1 - d_i . y_i per cell, weights r_i / (r . r)
 //            (the identity X[n-1, i] = r_i / (r.r)).
 // Same mathematics as dgels on the reference's matrix -- a Householder QR in a column order that exposes the zeros.
@@ -36,6 +46,14 @@ namespace nin {
 namespace {
 
 using namespace glsmath;
+
+// Diagnostic build (-DNIN_MFW_STAMPS, tools/stamps_mfw.py): wavefront 0 of workgroup 0 records s_memtime at the phase
+// boundaries of its 5th node into the neumann_ws entries of the first listed nodes instead of results.
+#ifdef NIN_MFW_STAMPS
+#define NIN_MFW_STAMP(J) do { if (stamping) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); stamps[J] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define NIN_MFW_STAMP(J) do { } while (0)
+#endif
 
 constexpr int STAGE_F = 70;   // per front: 7 fill rows x (9 neighbour columns + c)
 
@@ -201,7 +219,15 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         if (lane == 0) v = atomicAdd(queue, 1);
         return __builtin_amdgcn_readfirstlane(v);
     };
+#ifdef NIN_MFW_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int n_done = 0;
+#endif
     for (int32_t idx = ticket(); idx < count; idx = ticket()) {
+#ifdef NIN_MFW_STAMPS
+        const bool stamping = blockIdx.x == 0 && threadIdx.x < 64 && n_done == 4;
+#endif
+        NIN_MFW_STAMP(0);
         const int32_t p = __builtin_amdgcn_readfirstlane(nodes ? nodes[idx] : idx);
         const uint32_t *dw = desc + (size_t)kMfwDescWords * idx;
         const uint32_t fd = (uint32_t)__builtin_amdgcn_readfirstlane((int)dw[24]);
@@ -215,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         const uint32_t pe = w0 & 31, po = (w0 >> 21) & 31;
         const uint32_t frec[3] = {(w0 >> 5) & 0xFFFFu, w1 & 0xFFFFu, w1 >> 16};
 
+        NIN_MFW_STAMP(1);   // node, descriptor, CSR row starts read
         // ---- phase 1: the front of cell E_f in lane f (rows 0 = cell row, 1 + 3 i + r = row r of face i) -------------
         double u[9], se, de[3], dod[3];
         {
@@ -338,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         }
         // the dense cells' rows, (x_K - x_v) on the cell's own columns: column 3 d + t <- lane d's component t
         if (lane < D) { dbuf[3 * lane + 0] = dod[0]; dbuf[3 * lane + 1] = dod[1]; dbuf[3 * lane + 2] = dod[2]; }
+        NIN_MFW_STAMP(2);   // phase 1 done
         wave_lds_sync();
 
         const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
@@ -375,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
                 gather(lane < NP ? lane : 0, lane < NP, b, cb);
             }
             wave_lds_sync();          // the staging area is R's from here on
+            NIN_MFW_STAMP(3);   // rows gathered
             double dk = wave_allsum(fma(a[0], a[0], b[0] * b[0]));    // |column 0|^2; the later ones come out of the steps
             for (int k = 0; k < D; ++k) {
                 rows_block(a, b, ca, cb, dk, k, nc, lane, Rm, RP);
@@ -511,6 +540,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         }
         wave_lds_sync();
 
+        NIN_MFW_STAMP(4);   // dense problem factored
         // ---- R y = (Q^T c)(0:nc) by columns: lane = row ------------------------------------------------------------------
         {
             const int li = lane < nc ? lane : 0;
@@ -526,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
             if (lane < nc) yb[lane] = ct * ri;
         }
         wave_lds_sync();
+        NIN_MFW_STAMP(5);   // back-substitution done
         // ---- residuals on the cell rows, weights ---------------------------------------------------------------------------
         {
             double re = 1.0 - se;                                     // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_dense
@@ -553,9 +584,17 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
             const double nwv = is_neu ? wbuf[ne - 1] : 0.0;
             const double addv = add_neumann ? nwv : 0.0;
             if (lane < ne) out[eb + lane] = wbuf[lane] + addv;
+#ifndef NIN_MFW_STAMPS
             if (lane == 0) nws[p] = nwv;
+#endif
         }
         wave_lds_sync();
+        NIN_MFW_STAMP(6);   // weights stored
+#ifdef NIN_MFW_STAMPS
+        if (stamping && lane == 0)
+            for (int i = 0; i < 7; ++i) nws[nodes[i]] = (double)(stamps[i] - stamps[0]);   // (this build leaves neumann_ws to the stamps)
+        ++n_done;
+#endif
     }
 }
 

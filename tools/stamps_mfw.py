@@ -1,0 +1,20 @@
+"""Phase stamps (s_memtime) of the one-wavefront multifrontal GLS kernel on a Kuhn-tet node (needs a -DNIN_MFW_STAMPS build):
+NIN_EXTRA_HIPCC_FLAGS=-DNIN_MFW_STAMPS python -m ninpol_amd.build --force; python tools/stamps_mfw.py"""
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from ninpol_amd import mesh as M
+m = M.tet_mesh(24, jitter=0.1); M.attach_fields(m, "u", perm="ALH")
+import ninpol_amd
+I = ninpol_amd.Interpolator(); I.load_mesh(mesh_obj=m)
+w, nws = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+g = I.grid
+ne = np.diff(np.asarray(g.esup_ptr)); bp = np.asarray(g.boundary_points).astype(bool)
+first = np.nonzero((ne == 24) & ~bp)[0][:7]          # the first nodes of the kernel's list
+st = np.asarray(nws)[first]
+names = ["node, descriptor, CSR row starts", "phase 1 (loads, fronts in lanes)", "rows gathered into the lanes", "dense factorisation",
+         "back-substitution", "residuals, weights, stores"]
+print("one Kuhn-tet node, wavefront 0 of workgroup 0, its 5th node (cycles):")
+for i, n in enumerate(names):
+    print(f"  {n:36s} {st[i + 1] - st[i]:8.0f}")
+print(f"  {'node':36s} {st[6]:8.0f}")
