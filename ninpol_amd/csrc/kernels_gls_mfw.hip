@@ -6,11 +6,12 @@
 // internal face, a face row coupling exactly its two cells.  The cell graph is bipartite here: F "front" cells that
 // share no face (each with exactly 3 faces at the node) and D "dense" cells; every face joins a front to a dense cell.
 //
-//   phase 1  lane f < F = front f: the 3 Householder steps on the front cell's own columns touch only its 10 rows
-//            (cell row + 3 x 3 face rows) -- all F fronts at once, one per lane, no cross-lane traffic, exactly as the
-//            quad lanes of the hex8 kernel do it.  Each leaves 3 rows of R, folded at once into what the weights need
-//            of them (z = R_ee^-T d_e, u = z^T R_ed, s = z . b_e), and 7 fill rows over the 9 columns of its three
-//            dense neighbours + c, which go through LDS into
+//   phase 1  the 3 Householder steps on a front cell's own columns touch only its 10 rows (cell row + 3 x 3 face rows):
+//            all F fronts at once, in-lane as the quad lanes of the hex8 kernel do it, FOUR lanes per front -- each
+//            factors the 10 x 3 panel (redundantly) and applies it to one block of the front's other columns: c, or
+//            the three columns of one dense neighbour.  Each front leaves 3 rows of R, folded at once into what the
+//            weights need of them (z = R_ee^-T d_e, u = z^T R_ed, s = z . b_e), and 7 fill rows over the 9 columns
+//            of its three dense neighbours + c, which go through LDS into
 //   phase 2  the dense (7 F + D) x (3 D + 1) problem -- Kuhn tetrahedra: 96 x 37 -- in one wavefront's registers, no
 //            barrier, no partial sums (the block kernel spends 4 wavefronts, an LDS round trip per row and two workgroup
 //            barriers per step on the same sweep, and ~5 x the instructions).  Two forms:
@@ -232,24 +233,32 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         const uint32_t *dw = desc + (size_t)kMfwDescWords * idx;
         const uint32_t fd = (uint32_t)__builtin_amdgcn_readfirstlane((int)dw[24]);
         const int F = fd & 255, D = (fd >> 8) & 255;
+        // phase 1 works with FOUR lanes per front: lane 4 f + j applies the front's reflectors to c (j = 0) or to the
+        // columns of the front's neighbour j - 1; dense cell d's centroid is fetched by lane d
+        const int fq = (lane >> 2) < FM ? (lane >> 2) : 0, jq = lane & 3;
+        const uint32_t w0 = dw[fq], w1 = dw[12 + fq];
         const int fl = lane < FM ? lane : 0;
-        const uint32_t w0 = dw[fl], w1 = dw[12 + fl];
+        const uint32_t w0l = dw[fl], w1l = dw[12 + fl];   // word f in lane f: what the gathers shuffle
         const uint32_t eb = (uint32_t)__builtin_amdgcn_readfirstlane(g.esup_ptr[p]);
         const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane(g.fsup_ptr[p]);
         const bool is_neu = (__builtin_amdgcn_readfirstlane((int)g.flags[p]) & 2) != 0;
         const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1], xv2 = g.coords[3 * (size_t)p + 2];
-        const uint32_t pe = w0 & 31, po = (w0 >> 21) & 31;
+        const uint32_t pe = w0 & 31, po = (w0l >> 21) & 31;
         const uint32_t frec[3] = {(w0 >> 5) & 0xFFFFu, w1 & 0xFFFFu, w1 >> 16};
 
         NIN_MFW_STAMP(1);   // node, descriptor, CSR row starts read
         // ---- phase 1: the front of cell E_f in lane f (rows 0 = cell row, 1 + 3 i + r = row r of face i) -------------
-        double u[9], se, de[3], dod[3];
+        // u: this lane's block of u = z^T R_ed (3 columns), or s = z . b_e in u[0] of the c lane
+        double u[3], de[3], dod[3];
+        const int my = jq > 0 ? jq - 1 : 0;                      // this lane's face (the c lane computes face 0's neighbour side in vain)
+        const uint32_t myrec = jq <= 1 ? frec[0] : jq == 2 ? frec[1] : frec[2];
         {
             const uint32_t ce = (uint32_t)g.esup[eb + pe], co = (uint32_t)g.esup[eb + po];
-            double P[10][3], nb0[3][3], sav[3][2][3];
-            double Ke[9];
+            const uint32_t cm = (uint32_t)g.esup[eb + ((myrec >> 11) & 31)];
+            double P[10][3], B[10][3];
+            double Ke[9], Km[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Ke[k] = g.perm[9 * (size_t)ce + k];
+            for (int k = 0; k < 9; ++k) { Ke[k] = g.perm[9 * (size_t)ce + k]; Km[k] = g.perm[9 * (size_t)cm + k]; }
             const double dme = g.diff_mag[ce];
             de[0] = g.centroids[3 * (size_t)ce + 0] - xv0;      // gls.pyx:269-277
             de[1] = g.centroids[3 * (size_t)ce + 1] - xv1;
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
             dod[1] = g.centroids[3 * (size_t)co + 1] - xv1;
             dod[2] = g.centroids[3 * (size_t)co + 2] - xv2;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) P[0][t] = de[t];
+            for (int t = 0; t < 3; ++t) { P[0][t] = de[t]; B[0][t] = (jq == 0 && t == 0) ? 1.0 : 0.0; }   // c = e_0 on entry
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 // B = [K N; T1; tau T2] (gls.pyx:293-321), row = [-B_a | +B_b] (gls.pyx:340-356)
@@ -275,16 +284,19 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
                 eta = dmn > eta ? dmn : eta;
                 const double tj = face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
                 const double sg = ((frec[i] >> 10) & 1) ? -1.0 : 1.0;
-                const double *Kn = g.perm + 9 * (size_t)cn;
+                const bool mine = jq > 0 && my == i;
+                const double s0[3] = {sg * T0, sg * T1, sg * T2}, s1[3] = {sg * (tj * U0), sg * (tj * U1), sg * (tj * U2)};
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     P[1 + 3 * i][t] = sg * (Ke[t * 3 + 0] * N0 + Ke[t * 3 + 1] * N1 + Ke[t * 3 + 2] * N2);
-                    nb0[i][t] = -sg * (Kn[t * 3 + 0] * N0 + Kn[t * 3 + 1] * N1 + Kn[t * 3 + 2] * N2);
+                    P[2 + 3 * i][t] = s0[t];
+                    P[3 + 3 * i][t] = s1[t];
+                    // the neighbour's side of the face rows, in the lane that owns this face only (zero elsewhere)
+                    const double nb = -sg * (Km[t * 3 + 0] * N0 + Km[t * 3 + 1] * N1 + Km[t * 3 + 2] * N2);
+                    B[1 + 3 * i][t] = mine ? nb : 0.0;
+                    B[2 + 3 * i][t] = mine ? -s0[t] : 0.0;
+                    B[3 + 3 * i][t] = mine ? -s1[t] : 0.0;
                 }
-                sav[i][0][0] = sg * T0; sav[i][0][1] = sg * T1; sav[i][0][2] = sg * T2;
-                sav[i][1][0] = sg * (tj * U0); sav[i][1][1] = sg * (tj * U1); sav[i][1][2] = sg * (tj * U2);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) { P[2 + 3 * i][t] = sav[i][0][t]; P[3 + 3 * i][t] = sav[i][1][t]; }
             }
             // panel: three Householder steps on the own columns; v_k stays in P[k..9][k]
             double g3[3], rinv[3], z[3];
@@ -328,40 +340,20 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
             z[0] = de[0] * rinv[0];
             z[1] = fma(-P[0][1], z[0], de[1]) * rinv[1];
             z[2] = fma(-P[1][2], z[1], fma(-P[0][2], z[0], de[2])) * rinv[2];
-            // the reflectors on c and on the three neighbour blocks; rows 0..2 -> s, u; rows 3..9 -> the staging area
-            double *stg = Rm + (lane < F ? lane : 0) * STAGE_F;
-            const bool front_lane = lane < F;
-            {
-                double Bc[10][1];
-                Bc[0][0] = 1.0;                               // c = e_0 on entry: only the cell row carries a 1
-                apply_panel<1, true, false, false, false>(P, g3, Bc);
-                se = fma(z[2], Bc[2][0], fma(z[1], Bc[1][0], z[0] * Bc[0][0]));
-                if (front_lane) {
+            // the reflectors on this lane's block; rows 0..2 -> u (or s); rows 3..9 -> the staging area
+            __builtin_amdgcn_sched_barrier(0);
+            apply_panel<3, true, true, true, true>(P, g3, B);
 #pragma unroll
-                    for (int r = 0; r < 7; ++r) stg[r * 10 + 9] = Bc[3 + r][0];
+            for (int t = 0; t < 3; ++t) u[t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));
+            if ((lane >> 2) < F) {
+                double *stg = Rm + (lane >> 2) * STAGE_F + (jq == 0 ? 9 : 3 * my);
+#pragma unroll
+                for (int r = 0; r < 7; ++r) stg[r * 10] = B[3 + r][0];
+                if (jq > 0) {
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) { stg[r * 10 + 1] = B[3 + r][1]; stg[r * 10 + 2] = B[3 + r][2]; }
                 }
             }
-#define NIN_MFW_BLOCK(I, ZA, ZB, ZC)                                                                      \
-            {                                                                                             \
-                double B[10][3];                                                                          \
-                _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                           \
-                    B[1 + 3 * I][t] = nb0[I][t]; B[2 + 3 * I][t] = -sav[I][0][t]; B[3 + 3 * I][t] = -sav[I][1][t]; \
-                }                                                                                         \
-                apply_panel<3, false, ZA, ZB, ZC>(P, g3, B);                                              \
-                _Pragma("unroll") for (int t = 0; t < 3; ++t)                                             \
-                    u[3 * I + t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));                \
-                if (front_lane) {                                                                         \
-                    _Pragma("unroll") for (int r = 0; r < 7; ++r)                                         \
-                        _Pragma("unroll") for (int t = 0; t < 3; ++t) stg[r * 10 + 3 * I + t] = B[3 + r][t]; \
-                }                                                                                         \
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            NIN_MFW_BLOCK(0, true, false, false)
-            __builtin_amdgcn_sched_barrier(0);
-            NIN_MFW_BLOCK(1, false, true, false)
-            __builtin_amdgcn_sched_barrier(0);
-            NIN_MFW_BLOCK(2, false, false, true)
-#undef NIN_MFW_BLOCK
         }
         // the dense cells' rows, (x_K - x_v) on the cell's own columns: column 3 d + t <- lane d's component t
         if (lane < D) { dbuf[3 * lane + 0] = dod[0]; dbuf[3 * lane + 1] = dod[1]; dbuf[3 * lane + 2] = dod[2]; }
@@ -375,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
             static_assert(!ROWS_IN_LANES || (NP == 36 && NREG <= 64), "one row per lane and array");
             double a[36], b[36], ca, cb;
             {
-                const uint32_t w0all = w0, w1all = w1;
+                const uint32_t w0all = w0l, w1all = w1l;
                 auto gather = [&](int row, bool have, double (&x)[36], double &xc) {
                     const bool fill = row < 7 * FM;
                     const int f = fill ? (row * 37) >> 8 : 0, i = row - 7 * f, d = row - 7 * FM;
@@ -427,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
                     // (the slot computation below is the same for the 7 rows of a front: the compiler keeps one copy)
                     int j = -1;
                     if (f < F) {
-                        const uint32_t q0 = rl32(w0, f), q1 = rl32(w1, f);
+                        const uint32_t q0 = rl32(w0l, f), q1 = rl32(w1l, f);
                         const int s0 = (q0 >> 11) & 15, s1 = (q1 >> 6) & 15, s2 = (q1 >> 22) & 15;   // dense slots of the front's 3 neighbours
                         j = sc == s0 ? tc : j;
                         j = sc == s1 ? 3 + tc : j;
@@ -559,13 +551,13 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         NIN_MFW_STAMP(5);   // back-substitution done
         // ---- residuals on the cell rows, weights ---------------------------------------------------------------------------
         {
-            double re = 1.0 - se;                                     // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_dense
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int s = (frec[i] >> 6) & 15;
-#pragma unroll
-                for (int t = 0; t < 3; ++t) re = fma(u[3 * i + t], yb[3 * s + t], re);
-            }
+            // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_dense: the c lane brings 1 - s, the three others their block of u . y
+            const int sl = (myrec >> 6) & 15;
+            double part = fma(u[2], yb[3 * sl + 2], fma(u[1], yb[3 * sl + 1], u[0] * yb[3 * sl]));
+            part = jq == 0 ? 1.0 - u[0] : part;
+            part += dpp_mov<0xB1>(part);   // quad_perm [1,0,3,2]
+            part += dpp_mov<0x4E>(part);   // quad_perm [2,3,0,1]
+            const double re = part;
             const int ld = lane < D ? lane : 0;
             const double ro = 1.0 - fma(dod[2], yb[3 * ld + 2], fma(dod[1], yb[3 * ld + 1], dod[0] * yb[3 * ld]));
             const double rri = fast_rcp(rr);
@@ -574,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
             const bool ok = rr > 0.0;
             we = (ok && __builtin_isfinite(we)) ? we : 0.0;
             wo = (ok && __builtin_isfinite(wo)) ? wo : 0.0;
-            if (lane < F) wbuf[pe] = we;
+            if ((lane >> 2) < F && jq == 0) wbuf[pe] = we;
             if (lane < D) wbuf[po] = wo;
         }
         wave_lds_sync();
