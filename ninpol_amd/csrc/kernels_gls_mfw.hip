@@ -135,11 +135,13 @@ constexpr int kReduce4Lane[4] = {0, 32, 16, 48};   // where column i of a reduce
 __device__ constexpr int slot_reg(int S, int m, int q) {
     return m == 0 ? (q == 0 ? -1 : S + q) : m == 1 ? (q == 0 ? -2 : S + 3 + q) : S + 4 * m - 1 + q;
 }
-template <int S>
-__device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], double &ca, double &cb, double &dk, int t, int live,
+// NC = 3 DM columns.  TWO: the rows fill two arrays (large instantiation: 60 non-pivot rows in a[], 36 pivot rows in
+// b[]); otherwise all 7 FM + DM <= 64 rows sit in b[], pivot rows first (small instantiation: 48 rows), and a[] is unused.
+template <int NC, bool TWO, int S>
+__device__ __forceinline__ void rows_step(double (&a)[NC], double (&b)[NC], double &ca, double &cb, double &dk, int t, int live,
                                           int lane) {
     const bool live_b = lane > t, piv = lane == t;
-    const double xa = a[S];
+    const double xa = TWO ? a[S] : 0.0;
     const double alpha = rl64(b[S], t);
     const double sq = dk * fast_rsqrt(dk);                           // dk = |(alpha, x)|^2
     const double beta = -copysign(sq, alpha);
@@ -147,7 +149,7 @@ __device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], doub
     const double vk = alpha - beta;
     const double xb = piv ? vk : (live_b ? b[S] : 0.0);
     b[S] = piv ? beta : b[S];                                        // R(t, t); the rest of row t of R takes shape in the pivot lane's b[]
-    constexpr int NG = (36 - S) / 4 + 1;
+    constexpr int NG = (NC - S) / 4 + 1;
 #pragma unroll
     for (int m = 0; m < NG; ++m) {
         if (m > 1 && slot_reg(S, m, 0) >= live) continue;            // (wave-uniform) nothing but zeros in this group
@@ -155,35 +157,38 @@ __device__ __forceinline__ void rows_step(double (&a)[36], double (&b)[36], doub
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = slot_reg(S, m, q);
-            if (r == -1) p[q] = fma(xb, cb, xa * ca);
-            else if (r == -2) { const double bn = live_b ? b[S + 1] : 0.0; p[q] = fma(a[S + 1], a[S + 1], bn * bn); }
-            else if (r < 36) p[q] = fma(xb, b[r], xa * a[r]);
+            if (r == -1) p[q] = TWO ? fma(xb, cb, xa * ca) : xb * cb;
+            else if (r == -2) {
+                const double bn = live_b ? b[S + 1 < NC ? S + 1 : NC - 1] : 0.0;
+                p[q] = TWO ? fma(a[S + 1 < NC ? S + 1 : NC - 1], a[S + 1 < NC ? S + 1 : NC - 1], bn * bn) : bn * bn;
+            } else if (r < NC) p[q] = TWO ? fma(xb, b[r], xa * a[r]) : xb * b[r];
             else p[q] = 0.0;
         }
         const double tot = reduce4(p[0], p[1], p[2], p[3]), wu = tot * inv;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = slot_reg(S, m, q);
-            if (r >= 36) continue;
+            if (r >= NC) continue;
             if (r == -2) { dk = rl64(tot, kReduce4Lane[q]); continue; }
             const double wj = rl64(wu, kReduce4Lane[q]);
             if (r == -1) {
-                ca = fma(-xa, wj, ca);
+                if (TWO) ca = fma(-xa, wj, ca);
                 cb = fma(-xb, wj, cb);
             } else {
-                a[r] = fma(-xa, wj, a[r]);
+                if (TWO) a[r] = fma(-xa, wj, a[r]);
                 b[r] = fma(-xb, wj, b[r]);
             }
         }
     }
 }
 // three steps (one dense cell's columns), then the columns move down by three
-__device__ __forceinline__ void rows_block(double (&a)[36], double (&b)[36], double &ca, double &cb, double &dk, int k, int nc,
+template <int NC, bool TWO>
+__device__ __forceinline__ void rows_block(double (&a)[NC], double (&b)[NC], double &ca, double &cb, double &dk, int k, int nc,
                                            int lane, double *Rm, int RP) {
     const int live = nc - 3 * k;
-    rows_step<0>(a, b, ca, cb, dk, 3 * k + 0, live, lane);
-    rows_step<1>(a, b, ca, cb, dk, 3 * k + 1, live, lane);
-    rows_step<2>(a, b, ca, cb, dk, 3 * k + 2, live, lane);
+    rows_step<NC, TWO, 0>(a, b, ca, cb, dk, 3 * k + 0, live, lane);
+    rows_step<NC, TWO, 1>(a, b, ca, cb, dk, 3 * k + 1, live, lane);
+    rows_step<NC, TWO, 2>(a, b, ca, cb, dk, 3 * k + 2, live, lane);
     // A retired pivot row is never touched again (its entry of every later reflector is zero), so row t of R simply
     // stays in lane t's b[] -- until the columns move down.  The three that are about to leave, R(0 .. 3k+2, 3k .. 3k+2):
     if (lane < 3 * k + 3) {
@@ -191,12 +196,12 @@ __device__ __forceinline__ void rows_block(double (&a)[36], double (&b)[36], dou
         Rt[0] = b[0]; Rt[1] = b[1]; Rt[2] = b[2];
     }
 #pragma unroll
-    for (int i0 = 0; i0 < 36; i0 += 3) {
+    for (int i0 = 0; i0 < NC; i0 += 3) {
         if (i0 >= live) continue;                                    // (zeros would move onto zeros)
 #pragma unroll
         for (int i = i0; i < i0 + 3; ++i) {
-            a[i] = i + 3 < 36 ? a[i + 3] : 0.0;
-            b[i] = i + 3 < 36 ? b[i + 3] : 0.0;
+            if (TWO) a[i] = i + 3 < NC ? a[i + 3] : 0.0;
+            b[i] = i + 3 < NC ? b[i + 3] : 0.0;
         }
     }
 }
@@ -363,15 +368,16 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
         double rr;
         if constexpr (ROWS_IN_LANES) {
-            // ---- the dense problem, lane = ROW: lane r holds row NP + r (r < NREG) in a[], pivot row r (r < NP) in b[] -------
-            static_assert(!ROWS_IN_LANES || (NP == 36 && NREG <= 64), "one row per lane and array");
-            double a[36], b[36], ca, cb;
+            // ---- the dense problem, lane = ROW.  TWO arrays (large): lane r holds row NP + r (r < NREG) in a[] and pivot row
+            //      r (r < NP) in b[]; one array (small): lane r holds row r in b[], the pivot rows first --------------------------
+            constexpr bool TWO = NP + NREG > 64;
+            static_assert(NREG <= 64 && NP <= 64, "one row per lane and array");
+            double a[NP], b[NP], ca = 0.0, cb;
             {
-                const uint32_t w0all = w0l, w1all = w1l;
-                auto gather = [&](int row, bool have, double (&x)[36], double &xc) {
+                auto gather = [&](int row, bool have, double (&x)[NP], double &xc) {
                     const bool fill = row < 7 * FM;
                     const int f = fill ? (row * 37) >> 8 : 0, i = row - 7 * f, d = row - 7 * FM;
-                    const uint32_t q0 = (uint32_t)__shfl((int)w0all, f), q1 = (uint32_t)__shfl((int)w1all, f);
+                    const uint32_t q0 = (uint32_t)__shfl((int)w0l, f), q1 = (uint32_t)__shfl((int)w1l, f);
                     const int s0 = (q0 >> 11) & 15, s1 = (q1 >> 6) & 15, s2 = (q1 >> 22) & 15;   // dense slots of the front's 3 neighbours
                     const bool ok = have && (fill ? f < F : d < D);
                     const int fbase = f * STAGE_F + i * 10;
@@ -391,18 +397,22 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
                     }
                     xc = ok ? (fill ? Rm[fbase + 9] : 1.0) : 0.0;
                 };
-                gather(NP + lane, lane < NREG, a, ca);
-                gather(lane < NP ? lane : 0, lane < NP, b, cb);
+                if constexpr (TWO) {
+                    gather(NP + lane, lane < NREG, a, ca);
+                    gather(lane < NP ? lane : 0, lane < NP, b, cb);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) a[i] = 0.0;
+                    gather(lane < NP + NREG ? lane : 0, lane < NP + NREG, b, cb);
+                }
             }
             wave_lds_sync();          // the staging area is R's from here on
             NIN_MFW_STAMP(3);   // rows gathered
-            double dk = wave_allsum(fma(a[0], a[0], b[0] * b[0]));    // |column 0|^2; the later ones come out of the steps
-            for (int k = 0; k < D; ++k) {
-                rows_block(a, b, ca, cb, dk, k, nc, lane, Rm, RP);
-            }
+            double dk = wave_allsum(TWO ? fma(a[0], a[0], b[0] * b[0]) : b[0] * b[0]);   // |column 0|^2; the later ones come out of the steps
+            for (int k = 0; k < D; ++k) rows_block<NP, TWO>(a, b, ca, cb, dk, k, nc, lane, Rm, RP);
             if (lane < nc) Rm[lane * RP + nc] = cb;                  // (Q^T c)(0:nc), the last column of R
-            const double cbl = lane >= nc ? cb : 0.0;                // pivot rows that never got their turn (D < DM) count too
-            rr = wave_allsum(fma(ca, ca, cbl * cbl));                // r . r = |(Q^T c)(nc:)|^2
+            const double cbl = lane >= nc ? cb : 0.0;                // rows that never were pivot rows (one array; or D < DM) count too
+            rr = wave_allsum(TWO ? fma(ca, ca, cbl * cbl) : cbl * cbl);   // r . r = |(Q^T c)(nc:)|^2
         } else {
         // ---- the dense problem, lane = column: rows 0 .. NP-1 (fill rows of the first fronts) go to LDS, the others
         //      stay in the register pairs a[] ---------------------------------------------------------------------------------
@@ -617,8 +627,11 @@ int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc
     const int64_t cap = 2 * 256;   // <= 256 registers per lane: two 4-wave workgroups per CU are resident; persistent
     if (blocks > cap) blocks = cap;
     static const bool lane_columns = getenv("NIN_MFW_LANE_COLUMNS") != nullptr;   // A/B switch: the large instantiation's first form
-    if (small)
+    if (small && lane_columns)
         hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwSmallFronts, kMfwSmallDense, false>), dim3((unsigned)blocks), dim3(256), 0,
+                           stream, g, nodes, desc, count, add_neumann, out, nws, queue);
+    else if (small)
+        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwSmallFronts, kMfwSmallDense, true>), dim3((unsigned)blocks), dim3(256), 0,
                            stream, g, nodes, desc, count, add_neumann, out, nws, queue);
     else if (lane_columns)
         hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwMaxFronts, kMfwMaxDense, false>), dim3((unsigned)blocks), dim3(256), 0, stream,
