@@ -15,20 +15,21 @@
 //   phase 2  the dense (7 F + D) x (3 D + 1) problem -- Kuhn tetrahedra: 96 x 37 -- in one wavefront's registers, no
 //            barrier, no partial sums (the block kernel spends 4 wavefronts, an LDS round trip per row and two workgroup
 //            barriers per step on the same sweep, and ~5 x the instructions).  Two forms:
-//            lane = ROW (large instantiation, up to 12 + 12 cells): lane r holds a non-pivot row in a[36] and, r < 36,
-//              pivot row r in b[36], the columns are static register indices.  With v = the pivot column's entries and
+//            lane = ROW: lane r holds a non-pivot row in a[36] and, r < 36, pivot row r in b[36] (large instantiation,
+//              up to 12 + 12 cells; the small one -- wedge 6 + 6, cube 4 + 4 nodes -- has all its 48 rows in ONE array,
+//              pivot rows first); the columns are static register indices.  With v = the pivot column's entries and
 //              alpha - beta in the pivot lane, ONE reduction per column gives w_j = g (v . C_j), w_j goes to a scalar
 //              register pair and every row's update is one FMA per array.  Four columns are reduced together
 //              (v_permlane32_swap / v_permlane16_swap bring them into the four 16-lane rows of one register, a DPP row
 //              reduction finishes them); the arrays move down by three registers after every cell so that one step body
 //              serves all cells, column groups that hold only zeros being skipped; a retired pivot row keeps row t of
 //              R in its lane's registers, three columns of it are saved to LDS per cell.
-//            lane = COLUMN (small instantiation: wedge 6 + 6 and cube 4 + 4 nodes; the large one's first form, kept
-//              behind NIN_MFW_LANE_COLUMNS): a step broadcasts the pivot column's entry of a row with v_readlane,
-//              updates the row and accumulates the next pivot column's dots in the same pass; the non-pivot rows are
-//              register pairs, the 3 D pivot rows live in LDS where row t of R replaces pivot row t in place.
-//              v_readlane costs ~2 FP64 FMAs of issue time (tools/micro_readlane.hip), 4 of them per row and step:
-//              that is why the rows went into the lanes (tet40: 3.9 -> 2.0 ms);
+//            lane = COLUMN (the first form, kept behind NIN_MFW_LANE_COLUMNS as the A/B baseline): a step broadcasts
+//              the pivot column's entry of a row with v_readlane, updates the row and accumulates the next pivot
+//              column's dots in the same pass; the non-pivot rows are register pairs, the 3 D pivot rows live in LDS
+//              where row t of R replaces pivot row t in place.  v_readlane costs ~2 FP64 FMAs of issue time
+//              (tools/micro_readlane.hip), 4 of them per row and step: that is why the rows went into the lanes
+//              (tet40: 3.8 -> 1.8 ms, wedge60: 4.1 -> 2.95 ms);
 //   then     R y = Q^T c by columns (lane = row, R through LDS), r_i = 1 - d_i . y_i per cell, weights r_i / (r . r)
 //            (the identity X[n-1, i] = r_i / (r.r)).
 // Same mathematics as dgels on the reference's matrix -- a Householder QR in a column order that exposes the zeros.
