@@ -49,3 +49,59 @@ def test_cube_descriptor_rejects_other_graphs():
     # 3-regular, 8 vertices, 12 edges, but with triangles: two K4-minus-an-edge joined
     bad = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 4), (3, 5), (4, 5), (4, 6), (5, 7), (6, 7), (6, 7)]
     assert P.descriptor(cells, list(range(12)), {f: (cells[a], cells[b]) for f, (a, b) in enumerate(bad)}) is None
+
+
+def _model_vs_oracle(oracle_lib, mesh):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import proto_mfw as P
+    M.attach_fields(mesh, "u", perm="ALH")
+    o = oracle_lib.OracleInterpolator("port", threads=2)
+    o.load_mesh(mesh)
+    W, _ = o.prepare("gls", "u")
+    G = o.grid
+    v2i = o.variable_to_index
+    perm = o.cells_data[v2i["cells"]["permeability"]][:G.n_elems * 9].reshape(-1, 9)
+    dmag = o.cells_data[v2i["cells"]["diff_mag"]][:G.n_elems]
+    taken = other = 0
+    for p in range(G.n_points):
+        if G.boundary_points[p]:
+            continue
+        w = P.node_weights(p, G, perm, dmag)
+        if w is None:
+            other += 1
+            continue
+        ref = W[p, :len(w)]
+        assert np.abs(w - ref).max() <= 1e-12 * np.abs(ref).max(), p
+        taken += 1
+    return taken, other
+
+
+def test_one_wavefront_model_matches_oracle(oracle_lib):
+    """The numpy model of the one-wavefront multifrontal kernel (tools/proto_mfw.py: the arithmetic of
+    csrc/kernels_gls_mfw.hip -- two-colouring, fronts with their z / u / s folding, the dense problem with one reduction
+    per column and the pivot row updated by its own reflector, the tail) against the oracle: Kuhn tetrahedra (12 fronts +
+    12 dense cells), wedges (6 + 6), cube nodes (4 + 4); and which nodes of a mixed mesh it takes."""
+    assert _model_vs_oracle(oracle_lib, M.tet_mesh(3, jitter=0.1, seed=1)) == (8, 0)
+    assert _model_vs_oracle(oracle_lib, M.wedge_mesh(3, jitter=0.05, seed=1)) == (8, 0)
+    assert _model_vs_oracle(oracle_lib, M.hex_mesh(3, jitter=0.1, seed=1)) == (8, 0)
+    taken, other = _model_vs_oracle(oracle_lib, M.mixed_mesh(6, 4, 4, jitter=0.1, seed=1))
+    assert taken > 0 and other > 0      # pyramid apexes and the hex | pyramid | tet interfaces have odd cycles
+
+
+def test_two_colour_descriptor_rejects():
+    """descriptor(): the cube graph is taken with 4 fronts in esup order; a plain even cycle (bipartite, but its cells have
+    2 faces, not 3), an odd cycle and a node with a boundary face are refused."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import proto_mfw as P
+    cells = list(range(50, 58))
+    cube = [(a, b) for a in range(8) for b in range(a + 1, 8) if bin(a ^ b).count("1") == 1]
+    fc = {f: (cells[a], cells[b]) for f, (a, b) in enumerate(cube)}
+    fronts, dense, ff = P.descriptor(cells, list(range(12)), fc)
+    assert fronts == [0, 3, 5, 6] and dense == [1, 2, 4, 7] and all(len(x) == 3 for x in ff)
+    ring = [(i, (i + 1) % 6) for i in range(6)]
+    assert P.descriptor(cells[:6], list(range(6)), {f: (cells[a], cells[b]) for f, (a, b) in enumerate(ring)}) is None
+    tri = [(0, 1), (1, 2), (2, 0)]
+    assert P.descriptor(cells[:3], list(range(3)), {f: (cells[a], cells[b]) for f, (a, b) in enumerate(tri)}) is None
+    fcb = dict(fc)
+    fcb[0] = (cells[0], -1)
+    assert P.descriptor(cells, list(range(12)), fcb) is None
