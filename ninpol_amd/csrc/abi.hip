@@ -344,9 +344,10 @@ int nin_grid_to_device(nin_grid *g, int device) {
     // ---- GLS launch plan: bin nodes by the size of their least-squares system (classified on the device) ----
     g->node_class.assign((size_t)P, 0);
     std::vector<std::vector<int32_t>> lists(kGlsClasses);
-    std::vector<int32_t> hex8_list, mfw_list[2];
+    std::vector<int32_t> hex8_list, mfw_list[3];
     // debugging switches: keep nodes away from the hex8 kernel (bit 0) / the one-wavefront multifrontal kernel (bit 1)
-    const int use_group = (getenv("NIN_GLS_NO_GROUP") == nullptr ? 1 : 0) | (getenv("NIN_GLS_NO_MFW") == nullptr ? 2 : 0);
+    const int use_group = (getenv("NIN_GLS_NO_GROUP") == nullptr ? 1 : 0) | (getenv("NIN_GLS_NO_MFW") == nullptr ? 2 : 0) |
+                          (getenv("NIN_GLS_NO_MFW_GENERAL") == nullptr ? 4 : 0);   // (bit 2: the multifrontal kernel's general kind)
     const bool force_global = getenv("NIN_GLS_FORCE_GLOBAL") != nullptr;   // testing switch: systems in global scratch
     int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0}, cols_max[kGlsClasses] = {0};
     {
@@ -368,7 +369,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
     for (int64_t p = 0; p < P; ++p) {
         const uint8_t c = g->node_class[p];
         if (c == 255) hex8_list.push_back((int32_t)p);
-        else if (c == 254 || c == 253) mfw_list[254 - c].push_back((int32_t)p);
+        else if (c >= 252 && c <= 254) mfw_list[254 - c].push_back((int32_t)p);
         else lists[c].push_back((int32_t)p);
     }
     for (int c = 0; c < kGlsClasses; ++c) {
@@ -394,7 +395,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
             if (launch_hex8_desc(d.v, d.hex8.nodes, d.hex8.count, d.hex8_desc, nullptr)) return fail(NIN_EHIP, "hex8 descriptor kernel");
         }
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         d.mfw[i].count = (int32_t)mfw_list[i].size();
         const int32_t *lp = nullptr;
         if (d.mfw[i].count && (rc = dev_upload(d, &lp, mfw_list[i]))) return rc;
@@ -451,10 +452,10 @@ static int launch_hex8(DeviceGrid &d, const int32_t *nodes, const int32_t *desc,
     return launch_gls_hex8mf(d.v, nodes, desc, count, add_neumann, out, nws, d.gls_queue, stream);
 }
 
-// two-coloured nodes: the one-wavefront multifrontal kernel (work counters: ints 5, 6 of the queue block)
-static int launch_mfw(DeviceGrid &d, const int32_t *nodes, const uint32_t *desc, int32_t count, int small, int add_neumann,
+// the one-wavefront multifrontal kernel, kind 0 / 1 / 2 (work counters: ints 5, 6, 7 of the queue block)
+static int launch_mfw(DeviceGrid &d, const int32_t *nodes, const uint32_t *desc, int32_t count, int kind, int add_neumann,
                       double *out, double *nws, hipStream_t stream) {
-    return launch_gls_mfw(d.v, nodes, desc, count, small, add_neumann, out, nws, d.gls_queue + 5 + small, stream);
+    return launch_gls_mfw(d.v, nodes, desc, count, kind, add_neumann, out, nws, d.gls_queue + 5 + kind, stream);
 }
 
 // one GLS size class: the block kernel with the system in LDS, or the wave kernel on global scratch
@@ -491,7 +492,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else {
             HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
             rc = launch_hex8(d, d.hex8.nodes, d.hex8_desc, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
-            for (int i = 0; i < 2 && !rc; ++i)
+            for (int i = 0; i < 3 && !rc; ++i)
                 rc = launch_mfw(d, d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, i, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             for (int c = 0; c < kGlsClasses && !rc; ++c) {
                 rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
@@ -506,11 +507,11 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     HIP_TRY(hipMemsetAsync(dev_csr_data, 0, (size_t)d.nnz_e * 8, stream));
     HIP_TRY(hipMemsetAsync(dev_neumann_ws, 0, (size_t)P * 8, stream));
     if (n_targets == 0) return NIN_OK;
-    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 3 : 1);
+    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 4 : 1);
     for (int64_t i = 0; i < n_targets; ++i) {
         int c = method == NIN_METHOD_GLS ? g->node_class[targets[i]] : 0;
         if (c == 255) c = kGlsClasses;   // the hex8 kernel's class
-        else if (c == 254 || c == 253) c = kGlsClasses + 1 + (254 - c);   // the one-wavefront multifrontal kernel, large / small
+        else if (c >= 252 && c <= 254) c = kGlsClasses + 1 + (254 - c);   // the one-wavefront multifrontal kernel, kind 0 / 1 / 2
         lists[c].push_back((int32_t)targets[i]);
     }
     // one device buffer for all class lists, filled before the first launch: a per-class allocate / copy / free
@@ -525,7 +526,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     first[lists.size()] = flat.size();
     int32_t *dl0 = nullptr;
     const size_t n_hex8 = method == NIN_METHOD_GLS ? lists[kGlsClasses].size() : 0;   // + 4 descriptor words per cube node
-    const size_t n_mfw = method == NIN_METHOD_GLS ? lists[kGlsClasses + 1].size() + lists[kGlsClasses + 2].size() : 0;   // + 32 per two-coloured node (the two lists are adjacent)
+    const size_t n_mfw = method == NIN_METHOD_GLS ? lists[kGlsClasses + 1].size() + lists[kGlsClasses + 2].size() + lists[kGlsClasses + 3].size() : 0;   // + kMfwDescWords per node of the multifrontal kernel (the three lists are adjacent)
     HIP_TRY(hipMalloc((void **)&dl0, (flat.size() + 4 * n_hex8 + kMfwDescWords * n_mfw) * 4));
     int32_t *ddesc = dl0 + flat.size();
     uint32_t *dmfw = reinterpret_cast<uint32_t *>(ddesc + 4 * n_hex8);
@@ -714,13 +715,14 @@ const char *nin_kernel_name(int method) {
     return kernel_name_gls_hex8mf();   // dominant on hexahedron meshes; kernel_name_gls_block() covers the other nodes
 }
 
-int nin_gls_plan(const nin_grid *g, int64_t counts[8]) {
+int nin_gls_plan(const nin_grid *g, int64_t counts[9]) {
     if (!g || !counts) return fail(NIN_EINVAL, "NULL argument");
     if (g->d.device < 0 || g->d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
     for (int c = 0; c < kGlsClasses; ++c) counts[c] = g->d.gls[c].count;
     counts[5] = g->d.hex8.count;
     counts[6] = g->d.mfw[0].count;
     counts[7] = g->d.mfw[1].count;
+    counts[8] = g->d.mfw[2].count;
     return NIN_OK;
 }
 

@@ -80,8 +80,8 @@ struct DeviceGrid {
     } gls[kGlsClasses];
     GlsClass hex8;  // cube nodes (8 cells, 12 internal faces, cube cell graph): kernels_gls_hex8mf.hip
     int32_t *hex8_desc = nullptr;   // [4 * hex8.count] lane descriptors (hex8_desc.hpp)
-    GlsClass mfw[2];   // two-coloured nodes (mfw_desc.hpp: Kuhn tetrahedra, wedges, ...), large / small: kernels_gls_mfw.hip
-    uint32_t *mfw_desc[2] = {nullptr, nullptr};   // [32 * mfw[i].count] descriptor words
+    GlsClass mfw[3];   // kernels_gls_mfw.hip (mfw_desc.hpp): two-coloured nodes large (Kuhn tetrahedra) / small (wedges), general kind
+    uint32_t *mfw_desc[3] = {nullptr, nullptr, nullptr};   // [kMfwDescWords * mfw[i].count] descriptor words
     double *gls_scratch = nullptr;  // global-memory systems for the oversize class
     int64_t gls_scratch_stride = 0; // doubles per wave slot
     int32_t gls_scratch_slots = 0;

@@ -564,13 +564,15 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
         int32_t d[4];   // the hex8 kernel needs the cells to form the cube graph (hex8_desc.hpp)
         if (hex8_descriptor(g, (int32_t)p, d)) { node_class[p] = 255; return; }
     }
-    if ((use_group & 2) && nbf == 0 && ne <= kMfwMaxFronts + kMfwMaxDense) {
-        uint32_t w[kMfwDescWords];   // bipartite cell graph, fronts with 3 faces each (mfw_desc.hpp)
-        if (mfw_descriptor(g, (int32_t)p, w)) {
+    if ((use_group & 2) && nbf == 0 && ne <= kMfwMaxCells) {
+        uint32_t w[kMfwDescWords];   // fronts of 3-face cells that share no face + dense cells (mfw_desc.hpp)
+        const int kind = mfw_descriptor(g, (int32_t)p, w);
+        if (kind == 1) {
             const int F = w[24] & 255, D = (w[24] >> 8) & 255;
             node_class[p] = (F <= kMfwSmallFronts && D <= kMfwSmallDense) ? 253 : 254;
             return;
         }
+        if (kind == 2 && (use_group & 4)) { node_class[p] = 252; return; }
     }
     int64_t bytes, rows, cols;
     const int c = gls_node_class(ne, nf, nbf, force_global != 0, &bytes, &rows, &cols);

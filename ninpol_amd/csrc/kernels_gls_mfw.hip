@@ -59,16 +59,22 @@ using namespace glsmath;
 
 constexpr int STAGE_F = 70;   // per front: 7 fill rows x (9 neighbour columns + c)
 
-// Sizes for nodes with at most FM fronts and DM dense cells: 7 FM + DM dense rows -- the first NP = 3 DM of them (the
-// ones that get pivoted) live in LDS, where row t of R replaces pivot row t in place; the other NREG in registers.
-template <int FM, int DM>
+// Sizes for nodes with at most FM fronts, DM dense cells and (GENERAL) kMfwMaxFree free faces.  Dense rows: 7 per front,
+// then the D dense cells' rows, then 3 per free face (<= kMfwMaxRows in all).  ROWS_IN_LANES: rows 0 .. NP-1 (NP = 3 DM, the ones that get pivoted)
+// in b[], the next 64 in a[], the rest in b[]'s lanes from NP on.  Otherwise (the first form) the pivot rows live in LDS
+// -- row t of R replaces pivot row t in place -- and the other NREG in registers.
+template <int FM, int DM, bool ROWS_IN_LANES, bool GENERAL>
 struct MfwDims {
     static constexpr int NP = 3 * DM, NREG = 7 * FM - 2 * DM, DROW0 = 7 * FM, RP = 3 * DM + 1;
-    static constexpr int PAD = 8;   // zero rows behind the pivot rows: the LDS sweep runs in whole groups of 4 and reads one group ahead
-    static constexpr int LDS_R = ((NP + PAD) * RP > FM * STAGE_F ? (NP + PAD) * RP : FM * STAGE_F);   // R rows; phase 1's staging area lies under them
+    static constexpr int TOTAL = GENERAL ? kMfwMaxRows : 7 * FM + DM;
+    static constexpr int PAD = ROWS_IN_LANES ? 0 : 8;   // zero rows behind the pivot rows: the LDS sweep runs in whole groups of 4 and reads one group ahead
+    static constexpr int STAGE = FM * STAGE_F + (GENERAL ? 18 * kMfwMaxFree : 0);   // phase 1's staging area (fronts' fill rows, free faces' rows)
+    static constexpr int LDS_FS = FM * STAGE_F;
+    static constexpr int LDS_R = ((NP + PAD) * RP > STAGE ? (NP + PAD) * RP : STAGE);   // R rows; the staging area lies under them
     static constexpr int LDS_Y = LDS_R, LDS_D = LDS_Y + 3 * DM + 4, LDS_W = LDS_D + 3 * DM + 4, LDS_Z = LDS_W + FM + DM,
                          LDS_PER_WAVE = LDS_Z + 64;   // (LDS_Z: 64 zeros, what a lane without an entry in a fill row reads)
-    static_assert(NREG > 0 && NP % 2 == 0, "row split");
+    static_assert(NREG > 0 && NP % 2 == 0 || ROWS_IN_LANES, "row split");
+    static_assert(!GENERAL || (ROWS_IN_LANES && TOTAL <= 128 && NP <= 64 && FM * 4 + kMfwMaxFree <= 64 && 26 + kMfwMaxFree <= kMfwDescWords), "lanes");
 };
 
 __device__ __forceinline__ double rl64(double v, int lane) {
@@ -207,12 +213,12 @@ __device__ __forceinline__ void rows_block(double (&a)[NC], double (&b)[NC], dou
     }
 }
 
-template <int FM, int DM, bool ROWS_IN_LANES>
+template <int FM, int DM, bool ROWS_IN_LANES, bool GENERAL>
 __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                               const uint32_t *__restrict__ desc, int32_t count,
                                                               int add_neumann, double *__restrict__ out,
                                                               double *__restrict__ nws, int32_t *__restrict__ queue) {
-    using Dm = MfwDims<FM, DM>;
+    using Dm = MfwDims<FM, DM, ROWS_IN_LANES, GENERAL>;
     constexpr int NP = Dm::NP, NREG = Dm::NREG, RP = Dm::RP;
     __shared__ double lds_all[4][Dm::LDS_PER_WAVE];
     const int lane = threadIdx.x & 63;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         const int32_t p = __builtin_amdgcn_readfirstlane(nodes ? nodes[idx] : idx);
         const uint32_t *dw = desc + (size_t)kMfwDescWords * idx;
         const uint32_t fd = (uint32_t)__builtin_amdgcn_readfirstlane((int)dw[24]);
-        const int F = fd & 255, D = (fd >> 8) & 255;
+        const int F = fd & 255, D = (fd >> 8) & 255, nfree = GENERAL ? (fd >> 16) & 255 : 0;
         // phase 1 works with FOUR lanes per front: lane 4 f + j applies the front's reflectors to c (j = 0) or to the
         // columns of the front's neighbour j - 1; dense cell d's centroid is fetched by lane d
         const int fq = (lane >> 2) < FM ? (lane >> 2) : 0, jq = lane & 3;
@@ -249,7 +255,9 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane(g.fsup_ptr[p]);
         const bool is_neu = (__builtin_amdgcn_readfirstlane((int)g.flags[p]) & 2) != 0;
         const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1], xv2 = g.coords[3 * (size_t)p + 2];
-        const uint32_t pe = w0 & 31, po = (w0l >> 21) & 31;
+        uint32_t po = (w0l >> 21) & 31;
+        if (GENERAL && lane >= 12) po = (dw[25] >> (5 * ((lane < DM ? lane : 12) - 12))) & 31;   // dense cells 12 .. 14
+        const uint32_t pe = w0 & 31;
         const uint32_t frec[3] = {(w0 >> 5) & 0xFFFFu, w1 & 0xFFFFu, w1 >> 16};
 
         NIN_MFW_STAMP(1);   // node, descriptor, CSR row starts read
@@ -361,6 +369,36 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
                 }
             }
         }
+        if (GENERAL && lane >= 4 * FM && lane - 4 * FM < nfree) {
+            // a free face (both its cells dense): its three rows [-B_a | +B_b] (gls.pyx:293-356) go straight into the dense
+            // problem; lane 4 FM + q stages the rows of free face q
+            const int q = lane - 4 * FM;
+            const uint32_t fw = dw[26 + q];
+            const uint32_t f = (uint32_t)g.fsup[fb + (fw & 63)];
+            const uint32_t ca_ = (uint32_t)g.esup[eb + ((fw >> 14) & 31)], cb_ = (uint32_t)g.esup[eb + ((fw >> 19) & 31)];
+            const double N0 = (double)g.face_normal[3 * (size_t)f + 0], N1 = (double)g.face_normal[3 * (size_t)f + 1],
+                         N2 = (double)g.face_normal[3 * (size_t)f + 2];
+            const double T0 = xv0 - g.face_center[3 * (size_t)f + 0], T1 = xv1 - g.face_center[3 * (size_t)f + 1],
+                         T2 = xv2 - g.face_center[3 * (size_t)f + 2];
+            const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+            const double da = g.diff_mag[ca_], db = g.diff_mag[cb_];
+            double eta = 0.0;
+            eta = da > eta ? da : eta;
+            eta = db > eta ? db : eta;
+            const double tj = face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
+            const double *Ka = g.perm + 9 * (size_t)ca_, *Kb = g.perm + 9 * (size_t)cb_;
+            double *fs = Rm + Dm::LDS_FS + 18 * q;
+            const double Tv[3] = {T0, T1, T2}, Uv[3] = {tj * U0, tj * U1, tj * U2};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                fs[0 + t] = -(Ka[t * 3 + 0] * N0 + Ka[t * 3 + 1] * N1 + Ka[t * 3 + 2] * N2);
+                fs[3 + t] = Kb[t * 3 + 0] * N0 + Kb[t * 3 + 1] * N1 + Kb[t * 3 + 2] * N2;
+                fs[6 + t] = -Tv[t];
+                fs[9 + t] = Tv[t];
+                fs[12 + t] = -Uv[t];
+                fs[15 + t] = Uv[t];
+            }
+        }
         // the dense cells' rows, (x_K - x_v) on the cell's own columns: column 3 d + t <- lane d's component t
         if (lane < D) { dbuf[3 * lane + 0] = dod[0]; dbuf[3 * lane + 1] = dod[1]; dbuf[3 * lane + 2] = dod[2]; }
         NIN_MFW_STAMP(2);   // phase 1 done
@@ -371,21 +409,34 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
         if constexpr (ROWS_IN_LANES) {
             // ---- the dense problem, lane = ROW.  TWO arrays (large): lane r holds row NP + r (r < NREG) in a[] and pivot row
             //      r (r < NP) in b[]; one array (small): lane r holds row r in b[], the pivot rows first --------------------------
-            constexpr bool TWO = NP + NREG > 64;
-            static_assert(NREG <= 64 && NP <= 64, "one row per lane and array");
+            constexpr int TOTAL = Dm::TOTAL;
+            constexpr bool TWO = TOTAL > 64;
+            static_assert(TOTAL <= 128 && NP <= 64, "one row per lane and array");
             double a[NP], b[NP], ca = 0.0, cb;
             {
                 auto gather = [&](int row, bool have, double (&x)[NP], double &xc) {
-                    const bool fill = row < 7 * FM;
-                    const int f = fill ? (row * 37) >> 8 : 0, i = row - 7 * f, d = row - 7 * FM;
+                    const int free0 = Dm::DROW0 + D;                          // the free faces' rows follow the D dense cells' rows
+                    const bool fill = row < Dm::DROW0, free_row = GENERAL && row >= free0;
+                    const int f = fill ? (row * 37) >> 8 : 0, i = row - 7 * f, d = row - Dm::DROW0;
                     const uint32_t q0 = (uint32_t)__shfl((int)w0l, f), q1 = (uint32_t)__shfl((int)w1l, f);
-                    const int s0 = (q0 >> 11) & 15, s1 = (q1 >> 6) & 15, s2 = (q1 >> 22) & 15;   // dense slots of the front's 3 neighbours
-                    const bool ok = have && (fill ? f < F : d < D);
-                    const int fbase = f * STAGE_F + i * 10;
+                    int s0 = (q0 >> 11) & 15, s1 = (q1 >> 6) & 15, s2 = (q1 >> 22) & 15;   // dense slots of the front's 3 neighbours
+                    bool ok = have && (fill ? f < F : d < D);
+                    int fbase = f * STAGE_F + i * 10;
+                    if (GENERAL) {
+                        // a free face's row: its two cells' blocks (side a, side b) lie 3 apart in the staging area
+                        const int x = free_row ? row - free0 : 0, q = (x * 43) >> 7, rr = x - 3 * q;
+                        const uint32_t fw = dw[26 + (q < kMfwMaxFree ? q : 0)];
+                        if (free_row) {
+                            s0 = (fw >> 6) & 15; s1 = (fw >> 10) & 15; s2 = -1;
+                            fbase = Dm::LDS_FS + 18 * q + 6 * rr;
+                            ok = have && q < nfree;
+                        }
+                    }
+                    const bool via_slots = fill || free_row;
 #pragma unroll
                     for (int sj = 0; sj < DM; ++sj) {
                         int off = Dm::LDS_Z;                                  // zeros
-                        if (fill) {
+                        if (via_slots) {
                             off = s0 == sj ? fbase : off;
                             off = s1 == sj ? fbase + 3 : off;
                             off = s2 == sj ? fbase + 6 : off;
@@ -396,15 +447,16 @@ __global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const i
 #pragma unroll
                         for (int tt = 0; tt < 3; ++tt) x[3 * sj + tt] = Rm[off + tt];
                     }
-                    xc = ok ? (fill ? Rm[fbase + 9] : 1.0) : 0.0;
+                    xc = ok ? (fill ? Rm[fbase + 9] : free_row ? 0.0 : 1.0) : 0.0;
                 };
                 if constexpr (TWO) {
-                    gather(NP + lane, lane < NREG, a, ca);
-                    gather(lane < NP ? lane : 0, lane < NP, b, cb);
+                    gather(NP + lane, NP + lane < TOTAL, a, ca);
+                    const int rb = lane < NP ? lane : lane + 64;         // b[]: the pivot rows, then the rows a[] has no lane for
+                    gather(rb < TOTAL ? rb : 0, rb < TOTAL, b, cb);
                 } else {
 #pragma unroll
                     for (int i = 0; i < NP; ++i) a[i] = 0.0;
-                    gather(lane < NP + NREG ? lane : 0, lane < NP + NREG, b, cb);
+                    gather(lane < TOTAL ? lane : 0, lane < TOTAL, b, cb);
                 }
             }
             wave_lds_sync();          // the staging area is R's from here on
@@ -621,25 +673,22 @@ int launch_mfw_desc(const GridView &g, const int32_t *nodes, int32_t count, uint
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int small, int add_neumann,
+int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int kind, int add_neumann,
                    double *out, double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
     int64_t blocks = ((int64_t)count + 3) / 4;
     const int64_t cap = 2 * 256;   // <= 256 registers per lane: two 4-wave workgroups per CU are resident; persistent
     if (blocks > cap) blocks = cap;
-    static const bool lane_columns = getenv("NIN_MFW_LANE_COLUMNS") != nullptr;   // A/B switch: the large instantiation's first form
-    if (small && lane_columns)
-        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwSmallFronts, kMfwSmallDense, false>), dim3((unsigned)blocks), dim3(256), 0,
-                           stream, g, nodes, desc, count, add_neumann, out, nws, queue);
-    else if (small)
-        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwSmallFronts, kMfwSmallDense, true>), dim3((unsigned)blocks), dim3(256), 0,
-                           stream, g, nodes, desc, count, add_neumann, out, nws, queue);
-    else if (lane_columns)
-        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwMaxFronts, kMfwMaxDense, false>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                           g, nodes, desc, count, add_neumann, out, nws, queue);
-    else
-        hipLaunchKernelGGL((nin_gls_mfw_kernel<kMfwMaxFronts, kMfwMaxDense, true>), dim3((unsigned)blocks), dim3(256), 0, stream,
-                           g, nodes, desc, count, add_neumann, out, nws, queue);
+    static const bool lane_columns = getenv("NIN_MFW_LANE_COLUMNS") != nullptr;   // A/B switch: the first form of the dense phase
+#define NIN_MFW_LAUNCH(FMX, DMX, RL, GEN)                                                                               \
+    hipLaunchKernelGGL((nin_gls_mfw_kernel<FMX, DMX, RL, GEN>), dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, \
+                       count, add_neumann, out, nws, queue)
+    if (kind == 2) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwWideDense, true, true);
+    else if (kind == 1 && lane_columns) NIN_MFW_LAUNCH(kMfwSmallFronts, kMfwSmallDense, false, false);
+    else if (kind == 1) NIN_MFW_LAUNCH(kMfwSmallFronts, kMfwSmallDense, true, false);
+    else if (lane_columns) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, false, false);
+    else NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, true, false);
+#undef NIN_MFW_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -33,8 +33,9 @@ const char *kernel_name_gls_hex8mf();
 // the one-wavefront multifrontal kernel for two-coloured nodes (kernels_gls_mfw.hip); `desc` = 32 descriptor words per
 // list entry (mfw_desc.hpp, filled by launch_mfw_desc); `queue`: one zeroed device int (the work counter)
 int launch_mfw_desc(const GridView &g, const int32_t *nodes, int32_t count, uint32_t *desc, hipStream_t stream);
-// `small`: every listed node has at most kMfwSmallFronts fronts and kMfwSmallDense dense cells
-int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int small, int add_neumann,
+// `kind`: 0 = two-coloured nodes, 1 = those among them with at most kMfwSmallFronts fronts and kMfwSmallDense dense cells,
+// 2 = the general kind (free faces, up to kMfwWideDense dense cells)
+int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int kind, int add_neumann,
                    double *out, double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_mfw();
 // out[j] += nws[row(j)] for IDW / LS is a no-op (their neumann_ws is 0): nothing to launch.
@@ -49,7 +50,7 @@ int launch_apply(const GridView &g, const double *data, const double *u, double 
 int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values,
                         hipStream_t stream);
 
-// GLS launch plan (grid_device.hip): size class of every node (255 = the hex8 kernel, 254 / 253 = the one-wavefront multifrontal kernel, large / small instantiation) and, per class, the
+// GLS launch plan (grid_device.hip): size class of every node (255 = the hex8 kernel, 254 / 253 / 252 = the one-wavefront multifrontal kernel: two-coloured nodes large / small, general kind) and, per class, the
 // maxima of (bytes, rows, columns) as 3 * kGlsClasses unsigned 64-bit values; all DEVICE pointers
 int launch_classify(const GridView &g, int use_group, int force_global, uint8_t *node_class,
                     unsigned long long *class_max, hipStream_t stream);

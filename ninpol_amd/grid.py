@@ -174,7 +174,7 @@ class Grid:
 
     def gls_plan(self):
         """Nodes per GLS kernel of the device copy (nin_gls_plan): block kernel classes 1 / 2 / 4 / 8 wavefronts per
-        node and global scratch, the cube-node kernel, the one-wavefront multifrontal kernel (large, small)."""
-        counts = np.zeros(8, dtype=np.int64)
+        node and global scratch, the cube-node kernel, the one-wavefront multifrontal kernel (two-coloured nodes large / small, general kind)."""
+        counts = np.zeros(9, dtype=np.int64)
         _lib.check(_lib.load().nin_gls_plan(self._h, counts.ctypes.data_as(ctypes.c_void_p)))
-        return dict(zip(("block1", "block2", "block4", "block8", "scratch", "hex8", "mfw_large", "mfw_small"), counts.tolist()))
+        return dict(zip(("block1", "block2", "block4", "block8", "scratch", "hex8", "mfw_large", "mfw_small", "mfw_general"), counts.tolist()))

@@ -215,10 +215,40 @@ def test_gpu_block_kernel_where_mfw_would_run(oracle_lib, monkeypatch, kind):
         w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
         assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL, off
         assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL, off
-    assert plans[True]["mfw_large"] == 0 and plans[True]["mfw_small"] == 0
+    assert plans[True]["mfw_large"] == 0 and plans[True]["mfw_small"] == 0 and plans[True]["mfw_general"] == 0
     taken = plans[False]["mfw_large"] + plans[False]["mfw_small"]
     assert taken == {"tet": 4 ** 3, "wedge": 4 ** 3}.get(kind, taken) and taken > 0
+    # the general kind (free faces, up to 15 dense cells): the hex | pyramid | tet interfaces and pyramid apexes of the mix
+    assert (plans[False]["mfw_general"] > 0) == (kind == "mixed")
     assert sum(plans[False].values()) == sum(plans[True].values()) == I.grid.n_points
+
+
+def test_gpu_multifrontal_general_kind(oracle_lib, monkeypatch):
+    """Interior nodes whose cell graph has odd cycles (hex | pyramid and pyramid | tet interfaces: 16 and 26 cells) or
+    cells with 4 faces at the node (pyramid apexes): the one-wavefront multifrontal kernel's general kind -- fronts = a
+    maximal independent set of 3-face cells, the faces between two dense cells as free rows, up to 15 dense cells and 128 rows --
+    against the oracle, and against the block kernel that takes them when the kind is switched off."""
+    mesh = M.mixed_mesh(10, 5, 5, jitter=0.1, seed=11)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=5)
+    o = oracle_lib.OracleInterpolator("port", threads=4)
+    o.load_mesh(mesh)
+    wo, no = o.prepare("gls", "u")
+    got = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("NIN_GLS_NO_MFW_GENERAL", "1")
+        I = _interp()
+        I.load_mesh(mesh_obj=mesh)
+        I.grid.to_device(0)
+        plan = I.grid.gls_plan()
+        assert (plan["mfw_general"] == 0) == off and plan["mfw_large"] > 0
+        w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+        assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL, off
+        assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL, off
+        got[off] = plan
+    ne = np.diff(np.asarray(I.grid.esup_ptr))
+    bp = np.asarray(I.grid.boundary_points).astype(bool)
+    assert got[False]["mfw_general"] == int(np.sum(~bp & np.isin(ne, (7, 16, 26))))
 
 
 @pytest.mark.parametrize("sectors,layers", [(15, 3), (30, 3), (50, 2), (80, 2)])
