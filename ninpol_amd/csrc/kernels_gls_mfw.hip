@@ -1,10 +1,12 @@
-// kernels_gls_mfw.hip -- GLS weights of "two-coloured" nodes (mfw_desc.hpp: interior nodes of Kuhn-type tetrahedron
-// meshes, of wedge meshes, ...), gfx950: ONE wavefront per node, the whole factorisation in registers.
+// kernels_gls_mfw.hip -- GLS weights of interior nodes whose cells split into fronts and dense cells (mfw_desc.hpp:
+// Kuhn-type tetrahedron meshes, wedge meshes, the interfaces and pyramid apexes of mixed meshes, ...), gfx950: ONE
+// wavefront per node, the whole factorisation in registers.
 //
 // The system (gls.pyx:252-356) as in kernels_gls_hex8mf.hip: unknowns = a gradient per cell (3 columns) + the node
 // value (the column c that the last-row identity turns into a right-hand side); rows = one per cell and three per
-// internal face, a face row coupling exactly its two cells.  The cell graph is bipartite here: F "front" cells that
-// share no face (each with exactly 3 faces at the node) and D "dense" cells; every face joins a front to a dense cell.
+// internal face, a face row coupling exactly its two cells.  F "front" cells share no face (each has exactly 3 faces
+// at the node), the D others are "dense" cells; a face joins a front to a dense cell (all of them if the cell graph is
+// bipartite: the two-coloured kind) or two dense cells (a free face, general kind: its rows join the dense problem).
 //
 //   phase 1  the 3 Householder steps on a front cell's own columns touch only its 10 rows (cell row + 3 x 3 face rows):
 //            all F fronts at once, in-lane as the quad lanes of the hex8 kernel do it, FOUR lanes per front -- each

@@ -78,30 +78,34 @@ def _model_vs_oracle(oracle_lib, mesh):
 
 def test_one_wavefront_model_matches_oracle(oracle_lib):
     """The numpy model of the one-wavefront multifrontal kernel (tools/proto_mfw.py: the arithmetic of
-    csrc/kernels_gls_mfw.hip -- two-colouring, fronts with their z / u / s folding, the dense problem with one reduction
-    per column and the pivot row updated by its own reflector, the tail) against the oracle: Kuhn tetrahedra (12 fronts +
-    12 dense cells), wedges (6 + 6), cube nodes (4 + 4); and which nodes of a mixed mesh it takes."""
+    csrc/kernels_gls_mfw.hip -- two-colouring or the largest greedy independent set, fronts with their z / u / s folding,
+    free faces' rows, the dense problem with one reduction per column and the pivot row updated by its own reflector, the
+    tail) against the oracle: Kuhn tetrahedra (12 fronts + 12 dense cells), wedges (6 + 6), cube nodes (4 + 4), and the
+    mixed mesh whose interface and apex nodes are of the general kind (odd cycles, free faces, up to 15 dense cells)."""
     assert _model_vs_oracle(oracle_lib, M.tet_mesh(3, jitter=0.1, seed=1)) == (8, 0)
     assert _model_vs_oracle(oracle_lib, M.wedge_mesh(3, jitter=0.05, seed=1)) == (8, 0)
     assert _model_vs_oracle(oracle_lib, M.hex_mesh(3, jitter=0.1, seed=1)) == (8, 0)
     taken, other = _model_vs_oracle(oracle_lib, M.mixed_mesh(6, 4, 4, jitter=0.1, seed=1))
-    assert taken > 0 and other > 0      # pyramid apexes and the hex | pyramid | tet interfaces have odd cycles
+    assert taken > 0 and other == 0
 
 
-def test_two_colour_descriptor_rejects():
-    """descriptor(): the cube graph is taken with 4 fronts in esup order; a plain even cycle (bipartite, but its cells have
-    2 faces, not 3), an odd cycle and a node with a boundary face are refused."""
+def test_descriptor_kinds():
+    """descriptor(): the cube graph is two-coloured with 4 fronts in esup order; the same graph with one more face between
+    two of its dense cells is of the general kind (an odd cycle; that face is free); a plain cycle (its cells have 2 faces,
+    not 3) and a node with a boundary face are refused."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import proto_mfw as P
     cells = list(range(50, 58))
     cube = [(a, b) for a in range(8) for b in range(a + 1, 8) if bin(a ^ b).count("1") == 1]
     fc = {f: (cells[a], cells[b]) for f, (a, b) in enumerate(cube)}
-    fronts, dense, ff = P.descriptor(cells, list(range(12)), fc)
-    assert fronts == [0, 3, 5, 6] and dense == [1, 2, 4, 7] and all(len(x) == 3 for x in ff)
+    kind, fronts, dense, ff, free = P.descriptor(cells, list(range(12)), fc)
+    assert kind == 1 and fronts == [0, 3, 5, 6] and dense == [1, 2, 4, 7] and all(len(x) == 3 for x in ff) and not free
+    fc2 = dict(fc)
+    fc2[12] = (cells[1], cells[2])            # 0-1 and 0-2 are faces of the cube: 0-1-2 is a triangle now
+    kind, fronts, dense, ff, free = P.descriptor(cells, list(range(13)), fc2)
+    assert kind == 2 and len(free) >= 1 and all(len(x) == 3 for x in ff) and len(fronts) + len(dense) == 8
     ring = [(i, (i + 1) % 6) for i in range(6)]
     assert P.descriptor(cells[:6], list(range(6)), {f: (cells[a], cells[b]) for f, (a, b) in enumerate(ring)}) is None
-    tri = [(0, 1), (1, 2), (2, 0)]
-    assert P.descriptor(cells[:3], list(range(3)), {f: (cells[a], cells[b]) for f, (a, b) in enumerate(tri)}) is None
     fcb = dict(fc)
     fcb[0] = (cells[0], -1)
     assert P.descriptor(cells, list(range(12)), fcb) is None
