@@ -681,7 +681,7 @@ int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc
     int64_t blocks = ((int64_t)count + 3) / 4;
     const int64_t cap = 2 * 256;   // <= 256 registers per lane: two 4-wave workgroups per CU are resident; persistent
     if (blocks > cap) blocks = cap;
-    static const bool lane_columns = getenv("NIN_MFW_LANE_COLUMNS") != nullptr;   // A/B switch: the first form of the dense phase
+    const bool lane_columns = getenv("NIN_MFW_LANE_COLUMNS") != nullptr;   // A/B switch: the first form of the dense phase
 #define NIN_MFW_LAUNCH(FMX, DMX, RL, GEN)                                                                               \
     hipLaunchKernelGGL((nin_gls_mfw_kernel<FMX, DMX, RL, GEN>), dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, \
                        count, add_neumann, out, nws, queue)

@@ -223,6 +223,24 @@ def test_gpu_block_kernel_where_mfw_would_run(oracle_lib, monkeypatch, kind):
     assert sum(plans[False].values()) == sum(plans[True].values()) == I.grid.n_points
 
 
+@pytest.mark.parametrize("kind", ["tet", "wedge"])
+def test_gpu_multifrontal_first_form(oracle_lib, monkeypatch, kind):
+    """The one-wavefront multifrontal kernel's first form (lane = column, pivot rows in LDS), kept behind
+    NIN_MFW_LANE_COLUMNS as the A/B baseline of the row-lane form: still correct."""
+    monkeypatch.setenv("NIN_MFW_LANE_COLUMNS", "1")
+    mesh = M.tet_mesh(4, jitter=0.1, seed=7) if kind == "tet" else M.wedge_mesh(4, jitter=0.05, seed=7)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=4)
+    o = oracle_lib.OracleInterpolator("port", threads=4)
+    o.load_mesh(mesh)
+    wo, no = o.prepare("gls", "u")
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+    assert I.grid.gls_plan()["mfw_large" if kind == "tet" else "mfw_small"] == 27
+    assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL
+    assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
+
+
 def test_gpu_multifrontal_general_kind(oracle_lib, monkeypatch):
     """Interior nodes whose cell graph has odd cycles (hex | pyramid and pyramid | tet interfaces: 16 and 26 cells) or
     cells with 4 faces at the node (pyramid apexes): the one-wavefront multifrontal kernel's general kind -- fronts = a
