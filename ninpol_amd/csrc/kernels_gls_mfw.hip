@@ -216,7 +216,9 @@ __device__ __forceinline__ void rows_block(double (&a)[NC], double (&b)[NC], dou
 }
 
 template <int FM, int DM, bool ROWS_IN_LANES, bool GENERAL>
-__global__ __launch_bounds__(256, 2) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
+// (3 wavefronts per SIMD pay for the small instantiation -- wedge60 2.95 -> 2.72 ms, 160 B of spills; the large one spills
+//  inside its steps at 168 registers: 1.80 -> 2.32 ms)
+__global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                               const uint32_t *__restrict__ desc, int32_t count,
                                                               int add_neumann, double *__restrict__ out,
                                                               double *__restrict__ nws, int32_t *__restrict__ queue) {
@@ -679,7 +681,7 @@ int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc
                    double *out, double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
     int64_t blocks = ((int64_t)count + 3) / 4;
-    const int64_t cap = 2 * 256;   // <= 256 registers per lane: two 4-wave workgroups per CU are resident; persistent
+    const int64_t cap = (kind == 1 ? 3 : 2) * 256;   // persistent: the 4-wave workgroups that are resident (2 per CU at <= 256 registers, 3 at <= 168)
     if (blocks > cap) blocks = cap;
     const bool lane_columns = getenv("NIN_MFW_LANE_COLUMNS") != nullptr;   // A/B switch: the first form of the dense phase
 #define NIN_MFW_LAUNCH(FMX, DMX, RL, GEN)                                                                               \
