@@ -167,6 +167,15 @@ int nin_pack_connectivity(int32_t n_blocks, const int64_t *const *block_data, co
                           const int64_t *type_id, int64_t *connectivity, int64_t *element_types);
 int nin_pack_table_row(const double *src, int64_t n, int64_t src_cols, int64_t take, double *dst);
 int nin_diff_mag(const double *permeability, int64_t n_elems, double *diff_mag);
+/* 64-bit hash of ALL bytes of a table, OpenMP-parallel (is the permeability resident on the device still the caller's?
+ * the reference re-reads its tables on every call, interpolator.pyx:583-600). */
+int nin_hash64(const void *data, size_t bytes, uint64_t *out);
+
+/* Page-locked host memory for the arrays that come back over PCIe (nin_interpolate_csr_host's outputs: 57 GB/s into
+ * pinned memory against 10-15 GB/s into pageable memory on the MI355X box).  The reference returns ordinary numpy
+ * arrays (interpolator.pyx:622-628); ninpol_amd.Interpolator wraps these buffers as numpy arrays and recycles them. */
+int nin_host_alloc(size_t bytes, void **ptr);
+int nin_host_free(void *ptr);
 
 /* Algorithmic HBM bytes one nin_weights call moves for `method` over all nodes (DESIGN.md formula,
  * SURVEY 8d): used by bench.py for the roofline line. */

@@ -19,7 +19,7 @@ EXPORTS = (
     "nin_grid_array_info", "nin_grid_array_copy", "nin_device_count", "nin_grid_to_device", "nin_grid_device",
     "nin_fields_set", "nin_weights_device", "nin_weights_host", "nin_csr_compact_host", "nin_interpolate_csr_host", "nin_apply_host",
     "nin_apply_device", "nin_apply_fields_host", "nin_pack_connectivity", "nin_pack_table_row", "nin_diff_mag",
-    "nin_algorithmic_bytes", "nin_kernel_name", "nin_gls_plan",
+    "nin_algorithmic_bytes", "nin_kernel_name", "nin_gls_plan", "nin_host_alloc", "nin_host_free", "nin_hash64",
 )
 
 _lib = None
@@ -70,6 +70,9 @@ def load():
     L.nin_kernel_name.argtypes = [i32]
     L.nin_kernel_name.restype = cp
     L.nin_gls_plan.argtypes = [vp, vp]
+    L.nin_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.nin_host_free.argtypes = [vp]
+    L.nin_hash64.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
     _lib = L
     return L
 
@@ -83,3 +86,40 @@ def device_count():
     n = ctypes.c_int(0)
     rc = load().nin_device_count(ctypes.byref(n))
     return n.value if rc == NIN_OK else 0
+
+
+class PinnedPool:
+    """Page-locked host buffers (nin_host_alloc) handed out as numpy arrays and taken back when the last view of an
+    array dies: device-to-host copies into them run at PCIe rate, and pinning a gigabyte costs ~50 ms, so buffers are
+    kept (up to `keep_bytes`) for the next call.  Not thread-safe (neither is the Interpolator)."""
+
+    def __init__(self, keep_bytes=4 << 30):
+        self.free = []          # (bytes, address)
+        self.keep_bytes = keep_bytes
+
+    def empty(self, n, dtype):
+        import weakref
+        import numpy as np
+        nbytes = max(int(n) * np.dtype(dtype).itemsize, 1)
+        best = None
+        for i, (b, _) in enumerate(self.free):
+            if nbytes <= b <= 2 * nbytes + 4096 and (best is None or b < self.free[best][0]):
+                best = i
+        if best is not None:
+            size, addr = self.free.pop(best)
+        else:
+            p = ctypes.c_void_p()
+            check(load().nin_host_alloc(nbytes, ctypes.byref(p)))
+            size, addr = nbytes, p.value
+        owner = (ctypes.c_char * size).from_address(addr)
+        weakref.finalize(owner, self._release, size, addr)
+        return np.frombuffer(owner, dtype=dtype, count=int(n))
+
+    def _release(self, size, addr):
+        try:
+            if sum(b for b, _ in self.free) + size <= self.keep_bytes:
+                self.free.append((size, addr))
+            else:
+                load().nin_host_free(addr)
+        except Exception:       # interpreter shutdown
+            pass

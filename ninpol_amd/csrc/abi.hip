@@ -594,34 +594,37 @@ int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indpt
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipSetDevice(d.device));
     const int64_t P = g->h.n_points;
-    int32_t *cnt = nullptr, *ptr = nullptr, *di = nullptr;
-    double *dv = nullptr;
-    void *tmp = nullptr;
     size_t tmp_bytes = 0;
     int rc = NIN_OK;
-    auto cleanup = [&]() { (void)hipFree(cnt); (void)hipFree(ptr); (void)hipFree(di); (void)hipFree(dv); (void)hipFree(tmp); };
-#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    TRY_C(hipMalloc((void **)&cnt, (size_t)(P + 1) * 4));
-    TRY_C(hipMalloc((void **)&ptr, (size_t)(P + 1) * 4));
+#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+    // scratch of the compaction: owned by the grid, allocated on first use (sized by the mesh: P + 1 counters, nnz_e entries)
+    if (!d.e2e_cnt && (rc = dev_alloc(d, &d.e2e_cnt, (size_t)(P + 1)))) return rc;
+    if (!d.e2e_ptr && (rc = dev_alloc(d, &d.e2e_ptr, (size_t)(P + 1)))) return rc;
+    int32_t *cnt = d.e2e_cnt, *ptr = d.e2e_ptr;
     TRY_C(hipMemsetAsync(cnt, 0, (size_t)(P + 1) * 4, stream));
-    if ((rc = launch_row_nnz(d.v, dev_csr_data, cnt, stream))) { cleanup(); return fail(rc, "launch failed"); }
+    if ((rc = launch_row_nnz(d.v, dev_csr_data, cnt, stream))) return fail(rc, "launch failed");
     TRY_C(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, ptr, (int)(P + 1), stream));
-    TRY_C(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-    TRY_C(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, ptr, (int)(P + 1), stream));
+    if (tmp_bytes > d.e2e_tmp_bytes) {
+        char *t = nullptr;
+        if ((rc = dev_alloc(d, &t, std::max<size_t>(tmp_bytes, 16)))) return rc;   // (a smaller one stays in d.allocs until the grid goes)
+        d.e2e_tmp = t;
+        d.e2e_tmp_bytes = tmp_bytes;
+    }
+    TRY_C(hipcub::DeviceScan::ExclusiveSum(d.e2e_tmp, tmp_bytes, cnt, ptr, (int)(P + 1), stream));
     TRY_C(hipMemcpyAsync(indptr, ptr, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, stream));
     TRY_C(hipStreamSynchronize(stream));
     const int64_t nnz = indptr[P];
     *nnz_out = nnz;
     if (nnz > 0 && indices && data) {
-        TRY_C(hipMalloc((void **)&di, (size_t)nnz * 4));
-        TRY_C(hipMalloc((void **)&dv, (size_t)nnz * 8));
-        if ((rc = launch_compact(d.v, dev_csr_data, ptr, di, dv, stream))) { cleanup(); return fail(rc, "launch failed"); }
-        TRY_C(hipMemcpyAsync(indices, di, (size_t)nnz * 4, hipMemcpyDeviceToHost, stream));
-        TRY_C(hipMemcpyAsync(data, dv, (size_t)nnz * 8, hipMemcpyDeviceToHost, stream));
+        const size_t cap = (size_t)std::max<int64_t>(d.nnz_e, 1);
+        if (!d.e2e_indices && (rc = dev_alloc(d, &d.e2e_indices, cap))) return rc;
+        if (!d.e2e_data && (rc = dev_alloc(d, &d.e2e_data, cap))) return rc;
+        if ((rc = launch_compact(d.v, dev_csr_data, ptr, d.e2e_indices, d.e2e_data, stream))) return fail(rc, "launch failed");
+        TRY_C(hipMemcpyAsync(indices, d.e2e_indices, (size_t)nnz * 4, hipMemcpyDeviceToHost, stream));
+        TRY_C(hipMemcpyAsync(data, d.e2e_data, (size_t)nnz * 8, hipMemcpyDeviceToHost, stream));
         TRY_C(hipStreamSynchronize(stream));
     }
 #undef TRY_C
-    cleanup();
     return NIN_OK;
 }
 
@@ -631,19 +634,16 @@ int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *
     DeviceGrid &d = g->d;
     if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
     HIP_TRY(hipSetDevice(d.device));
-    const size_t nb = (size_t)std::max<int64_t>(d.nnz_e, 1) * 8, pb = (size_t)g->h.n_points * 8;
-    double *dd = nullptr, *dn = nullptr;
-    HIP_TRY(hipMalloc((void **)&dd, nb));
-    hipError_t e = hipMalloc((void **)&dn, pb);
-    if (e != hipSuccess) { (void)hipFree(dd); return fail(NIN_ENOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
-    int rc = nin_weights_device(g, method, nullptr, 0, 1, dd, dn, nullptr);
-    if (!rc) rc = nin_csr_compact_host(g, dd, indptr, indices, data, nnz_out, nullptr);
+    const size_t pb = (size_t)g->h.n_points * 8;
+    int rc = NIN_OK;
+    if (!d.e2e_weights && (rc = dev_alloc(d, &d.e2e_weights, (size_t)std::max<int64_t>(d.nnz_e, 1)))) return rc;
+    if (!d.e2e_nws && (rc = dev_alloc(d, &d.e2e_nws, (size_t)std::max<int64_t>(g->h.n_points, 1)))) return rc;
+    rc = nin_weights_device(g, method, nullptr, 0, 1, d.e2e_weights, d.e2e_nws, nullptr);
+    if (!rc) rc = nin_csr_compact_host(g, d.e2e_weights, indptr, indices, data, nnz_out, nullptr);
     if (!rc) {
-        e = hipMemcpy(neumann_ws, dn, pb, hipMemcpyDeviceToHost);
+        const hipError_t e = hipMemcpy(neumann_ws, d.e2e_nws, pb, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(NIN_EHIP, "copy back: %s", hipGetErrorString(e));
     }
-    (void)hipFree(dd);
-    (void)hipFree(dn);
     return rc;
 }
 
@@ -713,6 +713,21 @@ const char *nin_kernel_name(int method) {
     if (method == NIN_METHOD_IDW) return "nin_rows_kernel<0>";
     if (method == NIN_METHOD_LS) return "nin_rows_kernel<1>";
     return kernel_name_gls_hex8mf();   // dominant on hexahedron meshes; kernel_name_gls_block() covers the other nodes
+}
+
+int nin_host_alloc(size_t bytes, void **ptr) {
+    if (!ptr) return fail(NIN_EINVAL, "NULL argument");
+    *ptr = nullptr;
+    const hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(NIN_ENOMEM, "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    return NIN_OK;
+}
+
+int nin_host_free(void *ptr) {
+    if (!ptr) return NIN_OK;
+    const hipError_t e = hipHostFree(ptr);
+    if (e != hipSuccess) return fail(NIN_EHIP, "hipHostFree: %s", hipGetErrorString(e));
+    return NIN_OK;
 }
 
 int nin_gls_plan(const nin_grid *g, int64_t counts[9]) {

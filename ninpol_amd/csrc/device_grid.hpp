@@ -86,6 +86,12 @@ struct DeviceGrid {
     int64_t gls_scratch_stride = 0; // doubles per wave slot
     int32_t gls_scratch_slots = 0;
     int32_t *gls_queue = nullptr;   // [kGlsQueueInts]
+    // buffers of nin_interpolate_csr_host / nin_csr_compact_host, allocated on first use and kept (0.65 + 0.98 GB at
+    // 10 M cells; allocating and freeing them cost ~10 ms of every call)
+    double *e2e_weights = nullptr, *e2e_nws = nullptr, *e2e_data = nullptr;
+    int32_t *e2e_cnt = nullptr, *e2e_ptr = nullptr, *e2e_indices = nullptr;
+    void *e2e_tmp = nullptr;
+    size_t e2e_tmp_bytes = 0;
     double *apply_weights = nullptr;   // [nnz_e] weights of the last nin_apply_device (allocated on first use)
     bool gls_too_large = false;     // some node's system has more rows than the scratch kernel handles (1024)
 };

@@ -15,6 +15,7 @@
 // This translation unit is compiled with -ffp-contract=off: the reference is built for baseline
 // x86-64 (no FMA) and its float32 normals (grid.pyx:732-767) must be reproduced exactly.
 #include "grid_host.hpp"
+#include "host_threads.hpp"
 
 #include <omp.h>
 
@@ -43,7 +44,7 @@ inline bool elem_has_point(const int32_t *el, int n, int32_t p) {
 
 int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, const double *xyz, int coords_dim) {
     const int64_t E = n_elems, P = n_points;
-    if (num_threads > 0) omp_set_num_threads(num_threads);
+    omp_set_num_threads(num_threads > 0 ? num_threads : default_host_threads());   // (0: the CPUs this process may actually use)
     const bool timing = getenv("NIN_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {

@@ -2,10 +2,15 @@
 // compute_diffusion_magnitude do in Python loops in the reference (interpolator.pyx:255-451, 501-509; 7.1 s at 1 M
 // cells there), as OpenMP loops behind the C ABI.  Built with -ffp-contract=off: diff_mag must be the reference's
 // value bit for bit.
+#include <omp.h>
+
 #include <cstdint>
+#include <algorithm>
+#include <vector>
 #include <cstring>
 
 #include "../../include/ninpol_amd.h"
+#include "host_threads.hpp"
 
 extern "C" {
 
@@ -58,6 +63,43 @@ int nin_diff_mag(const double *permeability, int64_t n_elems, double *diff_mag) 
         const double x = 1 - (3 * 1.0 / tr);
         diff_mag[i] = x * x;
     }
+    return NIN_OK;
+}
+
+// Hash of a byte range, in parallel: 1 MiB chunks, each run through four multiply-rotate lanes over its 8-byte words
+// (the structure of xxHash64's stripe loop, own constants and finish), the chunk digests folded in order.  Used by
+// ninpol_amd.Interpolator to tell whether the permeability table on the device still is the caller's (the reference re-reads
+// its tables on every call, interpolator.pyx:583-600): ALL bytes are hashed -- a sample would miss an in-place edit.
+int nin_hash64(const void *data, size_t bytes, uint64_t *out) {
+    if ((!data && bytes) || !out) return NIN_EINVAL;
+    constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull;
+    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    auto mix = [&](uint64_t acc, uint64_t w) { return rotl(acc + w * P2, 31) * P1; };
+    auto avalanche = [&](uint64_t h) { h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32; return h; };
+    constexpr size_t CH = (size_t)1 << 20;
+    const size_t n_chunks = (bytes + CH - 1) / CH;
+    std::vector<uint64_t> part(n_chunks ? n_chunks : 1, 0);
+    const unsigned char *base = static_cast<const unsigned char *>(data);
+    // memory-bound: 16 threads saturate it; never more than the CPUs the process may use (host_threads.hpp)
+    const int nt = std::min(nin::default_host_threads(), 16);
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int64_t c = 0; c < (int64_t)n_chunks; ++c) {
+        const unsigned char *q = base + (size_t)c * CH;
+        const size_t len = std::min(CH, bytes - (size_t)c * CH);
+        uint64_t a0 = P1 + (uint64_t)c, a1 = P2, a2 = P3, a3 = P1 ^ P3;
+        size_t i = 0;
+        for (; i + 32 <= len; i += 32) {
+            uint64_t w[4];
+            std::memcpy(w, q + i, 32);
+            a0 = mix(a0, w[0]); a1 = mix(a1, w[1]); a2 = mix(a2, w[2]); a3 = mix(a3, w[3]);
+        }
+        uint64_t h = rotl(a0, 1) + rotl(a1, 7) + rotl(a2, 12) + rotl(a3, 18) + (uint64_t)len;
+        for (; i < len; ++i) h = rotl(h ^ (q[i] * P3), 11) * P1;
+        part[(size_t)c] = avalanche(h);
+    }
+    uint64_t h = P3 + (uint64_t)bytes;
+    for (size_t c = 0; c < n_chunks; ++c) h = mix(h, part[c]) ^ (h >> 29);
+    *out = avalanche(h);
     return NIN_OK;
 }
 

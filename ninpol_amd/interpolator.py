@@ -8,6 +8,7 @@ What is deliberately not reproduced (out of scope): the pickle grid c
 (interpolator.pyx:93-166,244-252) and the Logger class (plain prints behind `logging=`).
 """
 import ctypes
+import os
 import time
 
 import numpy as np
@@ -16,6 +17,8 @@ import scipy.sparse as sp
 from . import _lib
 from . import topology as T
 from .grid import Grid
+
+_pinned = _lib.PinnedPool()
 
 DTYPE_I = np.int64
 DTYPE_F = np.float64
@@ -60,16 +63,13 @@ class _MethodPlugin:
 
 
 def _table_key(a):
-    """Identity of a resident field table: address, size and a hash of ALL its bytes (xxh3, ~10 GB/s: 70 ms for the
-    0.7 GB permeability table of a 10 M-cell mesh) -- a strided sample would miss an in-place edit between samples
-    and leave a stale K on the device.  Without xxhash: zlib.crc32 over the whole table."""
-    try:
-        import xxhash
-        h = xxhash.xxh3_64_intdigest(memoryview(a).cast("B"))
-    except ImportError:   # pragma: no cover
-        import zlib
-        h = zlib.crc32(memoryview(a).cast("B"))
-    return (a.__array_interface__["data"][0], a.size, h)
+    """Identity of a resident field table: address, size and a hash of ALL its bytes (nin_hash64, OpenMP: ~5 ms for the
+    0.7 GB permeability table of a 10 M-cell mesh on 16 threads; single-threaded xxh3 took 30 ms of an 83 ms interpolate())
+    -- a strided sample would miss an in-place edit between samples and leave a stale K on the device."""
+    h = ctypes.c_uint64(0)
+    a = np.ascontiguousarray(a)
+    _lib.check(_lib.load().nin_hash64(_ptr(a), a.nbytes, ctypes.byref(h)))
+    return (a.__array_interface__["data"][0], a.size, h.value)
 
 
 def _upload_fields(grid, method, cells_data, points_data, variable_to_index, variable, device=0, always_perm=False):
@@ -349,10 +349,12 @@ class Interpolator:
             # device-side csr_matrix + eliminate_zeros (interpolator.pyx:622-624); only the surviving entries cross PCIe
             _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable)
             nnz_max = g.nnz_esup
-            indptr = np.empty(P + 1, dtype=np.int32)
-            indices = np.empty(nnz_max, dtype=np.int32)
-            data = np.empty(nnz_max, dtype=DTYPE_F)
-            nws = np.empty(P, dtype=DTYPE_F)
+            # the outputs land in page-locked buffers (57 against 10-15 GB/s over PCIe; recycled, see _lib.PinnedPool)
+            empty = np.empty if os.environ.get("NINPOL_AMD_NO_PINNED") else _pinned.empty
+            indptr = empty(P + 1, dtype=np.int32)
+            indices = empty(nnz_max, dtype=np.int32)
+            data = empty(nnz_max, dtype=DTYPE_F)
+            nws = empty(P, dtype=DTYPE_F)
             nnz = ctypes.c_int64(0)
             _lib.check(_lib.load().nin_interpolate_csr_host(g._h, _lib.METHOD_ID[method], _ptr(indptr), _ptr(indices),
                                                             _ptr(data), ctypes.byref(nnz), _ptr(nws)))
