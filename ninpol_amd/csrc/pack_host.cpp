@@ -12,6 +12,14 @@
 #include "../../include/ninpol_amd.h"
 #include "host_threads.hpp"
 
+namespace {
+// the library's default OpenMP team: the CPUs this process may use (host_threads.hpp), set once when the library loads
+// (OMP_NUM_THREADS and an explicit num_threads of nin_grid_create still win)
+struct DefaultTeam {
+    DefaultTeam() { omp_set_num_threads(nin::default_host_threads()); }
+} default_team;
+}  // namespace
+
 extern "C" {
 
 // interpolator.pyx:333-361: fixed-width -1 padded connectivity [n_elems][8] + element_types [n_elems] from per-type
