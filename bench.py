@@ -342,6 +342,11 @@ def main():
                               "frac_hbm": round(p2.algorithmic_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del out, nws
             torch.cuda.empty_cache()
+            # host-buffer (PCIe-inclusive) path, never `value`: the first call also pins its output buffers (recycled afterwards)
+            t0 = time.time()
+            W, _ = I.interpolate("u", args.method)
+            line["e2e_interpolate_first_s"] = round(time.time() - t0, 3)
+            del W
             t0 = time.time()
             W, _ = I.interpolate("u", args.method)
             line["e2e_interpolate_s"] = round(time.time() - t0, 3)
