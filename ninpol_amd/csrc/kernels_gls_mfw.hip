@@ -35,7 +35,8 @@
 //   then     R y = Q^T c by columns (lane = row, R through LDS), r_i = 1 - d_i . y_i per cell, weights r_i / (r . r)
 //            (the identity X[n-1, i] = r_i / (r.r)).
 // Same mathematics as dgels on the reference's matrix -- a Householder QR in a column order that exposes the zeros.
-// Two wavefronts per SIMD (<= 256 registers), 8 nodes in flight per CU against 2 for the block kernel.
+// Two wavefronts per SIMD (<= 256 registers; three for the small instantiation), 8 nodes in flight per CU against 2 for
+// the block kernel.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -62,9 +63,9 @@ using namespace glsmath;
 constexpr int STAGE_F = 70;   // per front: 7 fill rows x (9 neighbour columns + c)
 
 // Sizes for nodes with at most FM fronts, DM dense cells and (GENERAL) kMfwMaxFree free faces.  Dense rows: 7 per front,
-// then the D dense cells' rows, then 3 per free face (<= kMfwMaxRows in all).  ROWS_IN_LANES: rows 0 .. NP-1 (NP = 3 DM, the ones that get pivoted)
-// in b[], the next 64 in a[], the rest in b[]'s lanes from NP on.  Otherwise (the first form) the pivot rows live in LDS
-// -- row t of R replaces pivot row t in place -- and the other NREG in registers.
+// then the D dense cells' rows, then 3 per free face (<= kMfwMaxRows in all).  ROWS_IN_LANES: rows 0 .. NP-1 (NP = 3 DM,
+// the ones that get pivoted) in b[], the next 64 in a[], the rest in b[]'s lanes from NP on.  Otherwise (the first form)
+// the pivot rows live in LDS -- row t of R replaces pivot row t in place -- and the other NREG in registers.
 template <int FM, int DM, bool ROWS_IN_LANES, bool GENERAL>
 struct MfwDims {
     static constexpr int NP = 3 * DM, NREG = 7 * FM - 2 * DM, DROW0 = 7 * FM, RP = 3 * DM + 1;
