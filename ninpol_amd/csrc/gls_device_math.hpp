@@ -102,6 +102,53 @@ __device__ __attribute__((noinline)) static double face_tau(double un, double et
     return __builtin_amdgcn_ldexp(q, (int)k);
 }
 
+// The panel of a front: three Householder steps on the front cell's own columns (10 rows: the cell row and the 3 x 3
+// rows of its faces).  v_k stays in P[k..9][k] (pivot entries included), R's off-diagonal entries in P[0][1], P[0][2],
+// P[1][2]; g[k] = the reflectors' scalars, rinv[k] = 1 / R(k, k); z = R_ee^-T d: all the weights need of the front
+// cell's three rows of R.  Shared by kernels_gls_hex8mf.hip (a front per lane of the quad) and kernels_gls_mfw.hip.
+__device__ __forceinline__ void front_panel(double (&P)[10][3], const double (&d)[3], double (&g)[3], double (&z)[3]) {
+    double rinv[3];
+    {
+        double ss = 0.0;
+#pragma unroll
+        for (int r = 1; r < 10; ++r) ss = fma(P[r][0], P[r][0], ss);
+        const House h = house_unguarded(P[0][0], ss);
+        g[0] = h.g; rinv[0] = h.rinv;
+        double d1 = h.vp * P[0][1], d2 = h.vp * P[0][2];
+#pragma unroll
+        for (int r = 1; r < 10; ++r) { d1 = fma(P[r][0], P[r][1], d1); d2 = fma(P[r][0], P[r][2], d2); }
+        const double w1 = -(h.g * d1), w2 = -(h.g * d2);
+        P[0][0] = h.vp;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { P[r][1] = fma(w1, P[r][0], P[r][1]); P[r][2] = fma(w2, P[r][0], P[r][2]); }
+    }
+    {
+        double ss = 0.0;
+#pragma unroll
+        for (int r = 2; r < 10; ++r) ss = fma(P[r][1], P[r][1], ss);
+        const House h = house_unguarded(P[1][1], ss);
+        g[1] = h.g; rinv[1] = h.rinv;
+        double d2 = h.vp * P[1][2];
+#pragma unroll
+        for (int r = 2; r < 10; ++r) d2 = fma(P[r][1], P[r][2], d2);
+        const double w2 = -(h.g * d2);
+        P[1][1] = h.vp;
+#pragma unroll
+        for (int r = 1; r < 10; ++r) P[r][2] = fma(w2, P[r][1], P[r][2]);
+    }
+    {
+        double ss = 0.0;
+#pragma unroll
+        for (int r = 3; r < 10; ++r) ss = fma(P[r][2], P[r][2], ss);
+        const House h = house_unguarded(P[2][2], ss);
+        g[2] = h.g; rinv[2] = h.rinv;
+        P[2][2] = h.vp;
+    }
+    z[0] = d[0] * rinv[0];
+    z[1] = fma(-P[0][1], z[0], d[1]) * rinv[1];
+    z[2] = fma(-P[1][2], z[1], fma(-P[0][2], z[0], d[2])) * rinv[2];
+}
+
 // Computed HERE: without it the optimiser sinks a value's whole computation down to its first use -- for u, s and z
 // that is the end of the pass, with the rows of R they are made from parked in ~140 AGPRs across phase 2.
 __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }

@@ -339,49 +339,10 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
         nx.level0(nodes, desc, wg_next * NPW + nd, count, l, q, leader, (P[3][2] + P[6][2]) + P[9][2]);
         double C[NR][NC];
         double u[12], se;
-        double g3[3], rinv[3], z[3];
+        double g3[3], z[3];
         {
-            // ---- panel: three Householder steps on the own columns; v_k stays in P[k..9][k] ----------------------
-            {
-                double ss = 0.0;
-#pragma unroll
-                for (int r = 1; r < 10; ++r) ss = fma(P[r][0], P[r][0], ss);
-                const House h = house_unguarded(P[0][0], ss);
-                g3[0] = h.g; rinv[0] = h.rinv;
-                double d1 = h.vp * P[0][1], d2 = h.vp * P[0][2];
-#pragma unroll
-                for (int r = 1; r < 10; ++r) { d1 = fma(P[r][0], P[r][1], d1); d2 = fma(P[r][0], P[r][2], d2); }
-                const double w1 = -(h.g * d1), w2 = -(h.g * d2);
-                P[0][0] = h.vp;
-#pragma unroll
-                for (int r = 0; r < 10; ++r) { P[r][1] = fma(w1, P[r][0], P[r][1]); P[r][2] = fma(w2, P[r][0], P[r][2]); }
-            }
-            {
-                double ss = 0.0;
-#pragma unroll
-                for (int r = 2; r < 10; ++r) ss = fma(P[r][1], P[r][1], ss);
-                const House h = house_unguarded(P[1][1], ss);
-                g3[1] = h.g; rinv[1] = h.rinv;
-                double d2 = h.vp * P[1][2];
-#pragma unroll
-                for (int r = 2; r < 10; ++r) d2 = fma(P[r][1], P[r][2], d2);
-                const double w2 = -(h.g * d2);
-                P[1][1] = h.vp;
-#pragma unroll
-                for (int r = 1; r < 10; ++r) P[r][2] = fma(w2, P[r][1], P[r][2]);
-            }
-            {
-                double ss = 0.0;
-#pragma unroll
-                for (int r = 3; r < 10; ++r) ss = fma(P[r][2], P[r][2], ss);
-                const House h = house_unguarded(P[2][2], ss);
-                g3[2] = h.g; rinv[2] = h.rinv;
-                P[2][2] = h.vp;
-            }
-            // z = R_ee^-T d_e: all the weights need of the even cell's three rows of R
-            z[0] = de[0] * rinv[0];
-            z[1] = fma(-P[0][1], z[0], de[1]) * rinv[1];
-            z[2] = fma(-P[1][2], z[1], fma(-P[0][2], z[0], de[2])) * rinv[2];
+            // ---- panel: three Householder steps on the own columns; v_k stays in P[k..9][k]; z = R_ee^-T d_e -----------
+            front_panel(P, de, g3, z);
             pin(z[0]); pin(z[1]); pin(z[2]);
             // ---- the reflectors on the odd-slot blocks and on c, one block at a time.  Slot s takes face s (lanes with
             //      s < 3 - l) or face s - 1 (s > 3 - l).  Rows 0..2 of a finished block -> u = z^T R_eo (s = z . b_e for
