@@ -109,7 +109,8 @@ class PinnedPool:
             size, addr = self.free.pop(best)
         else:
             p = ctypes.c_void_p()
-            check(load().nin_host_alloc(nbytes, ctypes.byref(p)))
+            if load().nin_host_alloc(nbytes, ctypes.byref(p)) != 0 or not p.value:
+                return np.empty(int(n), dtype=dtype)      # no page-locked memory to be had: an ordinary array (slower copies)
             size, addr = nbytes, p.value
         owner = (ctypes.c_char * size).from_address(addr)
         weakref.finalize(owner, self._release, size, addr)
