@@ -147,18 +147,30 @@ __device__ constexpr int slot_reg(int S, int m, int q) {
 }
 // NC = 3 DM columns.  TWO: the rows fill two arrays (large instantiation: 60 non-pivot rows in a[], 36 pivot rows in
 // b[]); otherwise all 7 FM + DM <= 64 rows sit in b[], pivot rows first (small instantiation: 48 rows), and a[] is unused.
+// a reflector's scalars from its pivot entry alpha and dk = |(alpha, x)|^2: beta = R(t, t), vk = alpha - beta = v's pivot
+// entry, inv = g = 1 / (beta (beta - alpha))
+struct Reflector {
+    double beta, vk, inv;
+};
+__device__ __forceinline__ Reflector reflector(double alpha, double dk) {
+    const double sq = dk * fast_rsqrt(dk);
+    Reflector h;
+    h.beta = -copysign(sq, alpha);
+    h.inv = fast_rcp(fma(fabs(alpha), sq, dk));
+    h.vk = alpha - h.beta;
+    return h;
+}
+// `h`: this step's reflector on entry, the NEXT step's on exit -- its inputs (the next pivot column's norm, which rides in
+// the second column group, and the next pivot entry, updated in the first) are there long before this step ends, and
+// the ~25 dependent operations of its scalar chain overlap the remaining column groups instead of opening the next step.
 template <int NC, bool TWO, int S>
-__device__ __forceinline__ void rows_step(double (&a)[NC], double (&b)[NC], double &ca, double &cb, double &dk, int t, int live,
+__device__ __forceinline__ void rows_step(double (&a)[NC], double (&b)[NC], double &ca, double &cb, Reflector &h, int t, int live,
                                           int lane) {
     const bool live_b = lane > t, piv = lane == t;
     const double xa = TWO ? a[S] : 0.0;
-    const double alpha = rl64(b[S], t);
-    const double sq = dk * fast_rsqrt(dk);                           // dk = |(alpha, x)|^2
-    const double beta = -copysign(sq, alpha);
-    const double inv = fast_rcp(fma(fabs(alpha), sq, dk));           // g = 1 / (beta (beta - alpha))
-    const double vk = alpha - beta;
-    const double xb = piv ? vk : (live_b ? b[S] : 0.0);
-    b[S] = piv ? beta : b[S];                                        // R(t, t); the rest of row t of R takes shape in the pivot lane's b[]
+    const double inv = h.inv;
+    const double xb = piv ? h.vk : (live_b ? b[S] : 0.0);
+    b[S] = piv ? h.beta : b[S];                                      // R(t, t); the rest of row t of R takes shape in the pivot lane's b[]
     constexpr int NG = (NC - S) / 4 + 1;
 #pragma unroll
     for (int m = 0; m < NG; ++m) {
@@ -179,7 +191,10 @@ __device__ __forceinline__ void rows_step(double (&a)[NC], double (&b)[NC], doub
         for (int q = 0; q < 4; ++q) {
             const int r = slot_reg(S, m, q);
             if (r >= NC) continue;
-            if (r == -2) { dk = rl64(tot, kReduce4Lane[q]); continue; }
+            if (r == -2) {
+                h = reflector(rl64(b[S + 1 < NC ? S + 1 : NC - 1], t + 1), rl64(tot, kReduce4Lane[q]));
+                continue;
+            }
             const double wj = rl64(wu, kReduce4Lane[q]);
             if (r == -1) {
                 if (TWO) ca = fma(-xa, wj, ca);
@@ -193,12 +208,12 @@ __device__ __forceinline__ void rows_step(double (&a)[NC], double (&b)[NC], doub
 }
 // three steps (one dense cell's columns), then the columns move down by three
 template <int NC, bool TWO>
-__device__ __forceinline__ void rows_block(double (&a)[NC], double (&b)[NC], double &ca, double &cb, double &dk, int k, int nc,
+__device__ __forceinline__ void rows_block(double (&a)[NC], double (&b)[NC], double &ca, double &cb, Reflector &h, int k, int nc,
                                            int lane, double *Rm, int RP) {
     const int live = nc - 3 * k;
-    rows_step<NC, TWO, 0>(a, b, ca, cb, dk, 3 * k + 0, live, lane);
-    rows_step<NC, TWO, 1>(a, b, ca, cb, dk, 3 * k + 1, live, lane);
-    rows_step<NC, TWO, 2>(a, b, ca, cb, dk, 3 * k + 2, live, lane);
+    rows_step<NC, TWO, 0>(a, b, ca, cb, h, 3 * k + 0, live, lane);
+    rows_step<NC, TWO, 1>(a, b, ca, cb, h, 3 * k + 1, live, lane);
+    rows_step<NC, TWO, 2>(a, b, ca, cb, h, 3 * k + 2, live, lane);
     // A retired pivot row is never touched again (its entry of every later reflector is zero), so row t of R simply
     // stays in lane t's b[] -- until the columns move down.  The three that are about to leave, R(0 .. 3k+2, 3k .. 3k+2):
     if (lane < 3 * k + 3) {
@@ -427,8 +442,9 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
             }
             wave_lds_sync();          // the staging area is R's from here on
             NIN_MFW_STAMP(3);   // rows gathered
-            double dk = wave_allsum(TWO ? fma(a[0], a[0], b[0] * b[0]) : b[0] * b[0]);   // |column 0|^2; the later ones come out of the steps
-            for (int k = 0; k < D; ++k) rows_block<NP, TWO>(a, b, ca, cb, dk, k, nc, lane, Rm, RP);
+            // the first reflector: |column 0|^2 by a wave reduction (the later ones come out of the steps)
+            Reflector h = reflector(rl64(b[0], 0), wave_allsum(TWO ? fma(a[0], a[0], b[0] * b[0]) : b[0] * b[0]));
+            for (int k = 0; k < D; ++k) rows_block<NP, TWO>(a, b, ca, cb, h, k, nc, lane, Rm, RP);
             if (lane < nc) Rm[lane * RP + nc] = cb;                  // (Q^T c)(0:nc), the last column of R
             const double cbl = lane >= nc ? cb : 0.0;                // rows that never were pivot rows (one array; or D < DM) count too
             rr = wave_allsum(TWO ? fma(ca, ca, cbl * cbl) : cbl * cbl);   // r . r = |(Q^T c)(nc:)|^2
