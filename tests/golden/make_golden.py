@@ -31,6 +31,11 @@ CASES = {
     "tet3_jitter": (M.tet_mesh, dict(nx=3, jitter=0.1, seed=1), "ALH", (0, 0.0)),
     "wedge3_jitter": (M.wedge_mesh, dict(nx=3, jitter=0.1, seed=2), "ALH", (1, 1.0)),
     "mixed533_jitter": (M.mixed_mesh, dict(nx=5, ny=3, nz=3, n_hex=2, jitter=0.1, seed=4), "ALH", (2, 0.0)),
+    # round 3: the reference's own FAN tensor (tests/utils/analytical.py:285-293, cond(K) = 3e3, cond(M_v) = 7e4 here) with
+    # a Neumann plane; and BASELINE config [0]'s mesh exactly -- the Kuhn split of 6 x 6 x 5 hexahedra (E = 1 080, P = 294,
+    # SURVEY 8d), all-Dirichlet boundary
+    "hex8_fan": (M.hex_mesh, dict(nx=8, jitter=0.1, seed=6), "FAN", (2, 0.0)),
+    "tet665": (M.tet_mesh, dict(nx=6, ny=6, nz=5), "ALH", None),
 }
 
 
@@ -43,7 +48,10 @@ def build_case(name):
 
 def main():
     assert O.have_reference(), "build oracle/_ref first (python oracle/build_ref.py)"
+    only = sys.argv[1:]          # `make_golden.py hex8_fan tet665` regenerates just those
     for name in CASES:
+        if only and name not in only:
+            continue
         m = build_case(name)
         ref = O.OracleInterpolator("reference")
         ref.load_mesh(m)

@@ -379,6 +379,93 @@ def test_gpu_gls_degenerate_set(oracle_lib, kind):
     assert util.rowscaled_err(nw[regular], no[regular]) <= util.WEIGHT_RTOL
 
 
+# every way a node can reach a GLS kernel: name -> environment switches (read when the launch plan is built)
+_GLS_ROUTES = {
+    "default": (),                                                        # hex8mf / mfw (row lanes) / block for the rest
+    "no_cube_kernel": ("NIN_GLS_NO_GROUP",),                              # cube nodes -> mfw small instantiation
+    "mfw_lane_columns": ("NIN_GLS_NO_GROUP", "NIN_MFW_LANE_COLUMNS"),     # the mfw kernel's first form
+    "no_general_kind": ("NIN_GLS_NO_MFW_GENERAL",),                       # general-kind nodes -> block kernel
+    "block_only": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"),                 # block kernel, 1 / 2 / 4 / 8 wavefronts per node
+    "global_scratch": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_FORCE_GLOBAL"),   # the wave kernel
+}
+
+
+@pytest.mark.parametrize("kind", ["hex", "tet", "wedge", "mixed"])
+def test_gpu_gls_degenerate_zero_pivot_column(monkeypatch, kind):
+    """Degenerate class (iii) of the parity set: a pivot column that is zero altogether.  On
+    util.flat_mesh the z-column of EVERY cell is exactly zero in every node's system, so each computed node meets a zero
+    pivot column -- in the cube-node kernel as the NaN its branch-free Householder scalars produce (isfinite test), in the
+    mfw / block / wave kernels at their explicit guards.  The rule is ONE: the zero row, and neumann_ws = 0.  (The
+    reference reads what dgels' singular exit left in B there, gls.pyx:457-472 ignores `info`: outside the parity set.)
+    Every route to a kernel is forced in turn and must give exactly that, with the plan saying which kernel ran."""
+    mesh = util.flat_mesh(kind)
+    flag = mesh.point_data["neumann_flag_u"]
+    plans = {}
+    for route, switches in _GLS_ROUTES.items():
+        with monkeypatch.context() as mp:
+            for sw in switches:
+                mp.setenv(sw, "1")
+            I = _interp()
+            I.load_mesh(mesh_obj=mesh)
+            I.grid.to_device(0)
+            plans[route] = I.grid.gls_plan()
+            w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+        assert np.isfinite(np.asarray(I.grid.normal_faces)).all()
+        assert not np.any(w), (route, int(np.count_nonzero(np.abs(w).max(axis=1))))
+        assert not np.any(nw), route
+        # IDW / LS are untouched by any of this: rows of the computed nodes are there
+        W, _ = I.interpolate("u", "idw")
+        computed = ~(np.asarray(I.grid.boundary_points).astype(bool) & (flag == 0))
+        assert np.array_equal(np.diff(W.indptr) > 0, computed)
+    d = plans["default"]
+    assert (d["hex8"] > 0) == (kind in ("hex", "mixed"))
+    assert (d["mfw_large"] > 0) == (kind in ("tet", "mixed")) and (d["mfw_small"] > 0) == (kind == "wedge")
+    assert (d["mfw_general"] > 0) == (kind == "mixed")
+    assert plans["no_cube_kernel"]["hex8"] == 0 and plans["no_cube_kernel"]["mfw_small"] >= d["hex8"]
+    assert plans["no_general_kind"]["mfw_general"] == 0
+    for route in ("block_only", "global_scratch"):
+        assert all(plans[route][k] == 0 for k in ("hex8", "mfw_large", "mfw_small", "mfw_general")), route
+    assert all(sum(p.values()) == I.grid.n_points for p in plans.values())
+
+
+@pytest.mark.parametrize("n", [32, 64])
+def test_gpu_gls_fan_permeability(oracle_lib, n):
+    """The reference's own FAN tensor (tests/utils/analytical.py:285-293), element by element: cond(M_v) = 3e5 .. 6e5
+    here, so two correct QR codes differ by ~cond * eps.  The HIP path must be no further from the C restatement than the
+    restatement is from the reference itself (util.FAN_PORT_VS_REFERENCE, measured with oracle/_ref in the dev container
+    on exactly this mesh) and never looser than that; IDW / LS do not see K and keep their bit-level bar."""
+    mesh = M.hex_mesh(n, jitter=0.15, seed=0)
+    M.attach_fields(mesh, "u", perm="FAN", neumann_plane=(2, 0.0), seed=7)
+    o = oracle_lib.OracleInterpolator("port", threads=16)
+    o.load_mesh(mesh)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    full = np.arange(I.grid.n_points)
+    for meth in ("gls", "idw", "ls"):
+        wo, no = o.prepare(meth, "u")
+        w, nw = I.prepare_interpolator(meth, "u", full)
+        tol = util.fan_rtol(n) if meth == "gls" else TIGHT
+        e = max(util.rowscaled_err(w, wo), util.rowscaled_err(nw, no))
+        print(f"FAN hex {n}^3 {meth}: HIP vs port {e:.3e} (bound {tol:.2e})")
+        assert e <= tol, (meth, e)
+    # the same nodes through the generic kernels (cube-node kernel off): the bound is a property of the case, not of a kernel
+    if n == 32:
+        import os
+        for switches in (("NIN_GLS_NO_GROUP",), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW")):
+            for sw in switches:
+                os.environ[sw] = "1"
+            try:
+                J = _interp()
+                J.load_mesh(mesh_obj=mesh)
+                w, nw = J.prepare_interpolator("gls", "u", full)
+            finally:
+                for sw in switches:
+                    del os.environ[sw]
+            assert J.grid.gls_plan()["hex8"] == 0
+            wo, no = o.prepare("gls", "u")
+            assert max(util.rowscaled_err(w, wo), util.rowscaled_err(nw, no)) <= util.fan_rtol(n), switches
+
+
 def test_gpu_integration_md_plugin_stub_runs_verbatim():
     """the ctypes plugin a ninpol maintainer would add is executed as printed (only the
     library path is made absolute) against ninpol's 9-argument plugin convention, and must fill the dense

@@ -10,18 +10,27 @@ import pytest
 
 from ninpol_amd import mesh as M
 
-PUBLISHED = {   # accuracy.yaml <case>.hexa.methods.<method>.error[0:4]  (n = 4, 8, 16, 32)
-    "QUAD": {"gls": [0.049597505344958166, 0.011301539525229715, 0.0027087099593765705, 0.000663655487720301],
-             "idw": [0.04959750534495812, 0.011301539525229604, 0.0027087099593768533, 0.0006636554877206842],
-             "ls": [0.04959750534495812, 0.011301539525229604, 0.0027087099593768533, 0.0006636554877206842]},
-    "FAN": {"gls": [0.6464825197536167, 0.21142198013427013, 0.05654369856849046, 0.014376372221811547],
-            "idw": [0.6464466094067263, 0.21141949252526263, 0.056543636621940764, 0.014376371062800066],
-            "ls": [0.6464466094067263, 0.21141949252526263, 0.056543636621940764, 0.014376371062800066]},
-    "ALH": {"gls": [0.5722911516651576, 0.20457689362704667, 0.058306975035910105, 0.015267934836083682],
-            "idw": [0.5661291907242967, 0.209254302503144, 0.059559119987303635, 0.015534625204356821],
-            "ls": [0.5661291907242967, 0.209254302503144, 0.059559119987303635, 0.015534625204356821]},
+PUBLISHED = {   # accuracy.yaml <case>.hexa.methods.<method>.error[0:6]  (n = 4, 8, 16, 32, 64, 128: every size it lists)
+    "QUAD": {"gls": [0.049597505344958166, 0.011301539525229715, 0.0027087099593765705, 0.000663655487720301,
+                     0.00016428438670473602, 4.087104927582657e-05],
+             "idw": [0.04959750534495812, 0.011301539525229604, 0.0027087099593768533, 0.0006636554877206842,
+                     0.00016428438670435493, 4.087104927587358e-05],
+             "ls": [0.04959750534495812, 0.011301539525229604, 0.0027087099593768533, 0.0006636554877206842,
+                    0.00016428438670435493, 4.087104927587358e-05]},
+    "FAN": {"gls": [0.6464825197536167, 0.21142198013427013, 0.05654369856849046, 0.014376372221811547,
+                    0.003609280374535744, 0.0009032718084930065],
+            "idw": [0.6464466094067263, 0.21141949252526263, 0.056543636621940764, 0.014376371062800066,
+                    0.003609280354925421, 0.0009032718081743021],
+            "ls": [0.6464466094067263, 0.21141949252526263, 0.056543636621940764, 0.014376371062800066,
+                   0.003609280354925421, 0.0009032718081743021]},
+    "ALH": {"gls": [0.5722911516651576, 0.20457689362704667, 0.058306975035910105, 0.015267934836083682,
+                    0.0038890221023200108, 0.0009810113669126213],
+            "idw": [0.5661291907242967, 0.209254302503144, 0.059559119987303635, 0.015534625204356821,
+                    0.003941778851732194, 0.000991137038873931],
+            "ls": [0.5661291907242967, 0.209254302503144, 0.059559119987303635, 0.015534625204356821,
+                   0.003941778851732194, 0.000991137038873931]},
 }
-SIZES = [4, 8, 16, 32]
+SIZES = [4, 8, 16, 32, 64, 128]
 
 
 def solution(case, x, y, z):
@@ -53,7 +62,7 @@ def l2_internal(W, u, exact, internal):
 
 @pytest.mark.parametrize("case", ["QUAD", "FAN", "ALH"])
 def test_published_accuracy_oracle(oracle_lib, case):
-    for i, n in enumerate(SIZES[:3]):
+    for i, n in enumerate(SIZES[:4]):
         mesh, u, exact, internal = make_case(case, n)
         o = oracle_lib.OracleInterpolator("port", threads=2)
         o.load_mesh(mesh)
@@ -75,8 +84,9 @@ def test_lin_exact_oracle(oracle_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["QUAD", "FAN", "ALH"])
 def test_published_accuracy_gpu(case):
-    """The same published numbers through the HIP path and the C-ABI -- no oracle in between -- at all four mesh sizes
-    the reference lists (n = 4 .. 32), and the device-side apply beside the scipy product."""
+    """The same published numbers through the HIP path and the C-ABI -- no oracle in between -- at all six mesh sizes
+    the reference lists (n = 4 .. 128: 2 097 152 cells, the reference's largest published mesh), and the device-side
+    apply beside the scipy product."""
     import ninpol_amd
     for i, n in enumerate(SIZES):
         mesh, u, exact, internal = make_case(case, n)

@@ -23,7 +23,7 @@ for case in range(n_cases):
     elif kind == "mixed": m = M.mixed_mesh(max(nx, 4) + 2, ny, nz, jitter=min(jit, 0.1), seed=seed)
     else: m = M.wedge_fan(int(rng.integers(5, 70)), int(rng.integers(2, 4)), jitter=0.02, seed=seed)
     plane = None if rng.random() < 0.3 else (int(rng.integers(0, 3)), float(rng.integers(0, 2)))
-    perm = ["ALH", "LIN"][int(rng.integers(0, 2))]
+    perm = ["ALH", "LIN", "FAN"][int(rng.integers(0, 3))]
     M.attach_fields(m, "u", perm=perm, neumann_plane=plane, seed=seed % 1000)
     o = O.OracleInterpolator("port", threads=8); o.load_mesh(m)
     I = ninpol_amd.Interpolator(grid_build=["host", "device"][case % 2]); I.load_mesh(mesh_obj=m)
