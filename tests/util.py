@@ -21,16 +21,29 @@ WEIGHT_RTOL = 1e-10
 
 # The reference's own FAN tensor (tests/utils/analytical.py:285-293; cond(K) = 3.0e3) makes the GLS matrix M_v
 # ill-conditioned: cond(M_v) = 7e4 on hex 8^3, 3e5 on 32^3, ~6e5 on 64^3 (tools/gls_condition.py; it grows like 1/h:
-# the K.N rows do not scale with the mesh, the d / T / U rows do).  Two correct Householder codes then differ by
-# ~cond * eps: the C restatement against the REFERENCE ITSELF (oracle/_ref, SciPy's dgels), measured in the dev
-# container on hex_mesh(n, jitter=0.15, seed=0), Neumann plane z = 0 (row-scaled, the same measure as WEIGHT_RTOL):
-FAN_PORT_VS_REFERENCE = {8: 1.6e-11, 16: 4.8e-11, 32: 8.0e-11, 64: 1.85e-10}
-# so on THIS case only the HIP path is held to "no further from the port than the port is from the reference", and
-# never tighter than the global bar.  Every other case keeps WEIGHT_RTOL.
+# the K.N rows do not scale with the mesh, the d / T / U rows do).  Every correct float64 QR is then ~cond * eps away
+# from the exact least-squares solution -- THE REFERENCE INCLUDED: measured in the dev container on
+# hex_mesh(n, jitter=0.15, seed=0), Neumann plane z = 0, row-scaled like WEIGHT_RTOL (tests/golden/make_fan_exact.py;
+# `exact` = the same float64 matrix solved in 80-bit arithmetic):
+#     n    reference vs exact    C restatement vs exact    restatement vs reference (all nodes)
+#     32   4.1e-11               3.6e-11                   8.0e-11
+#     64   9.0e-11               1.07e-10                  1.85e-10
+# Two such codes can differ by the SUM of their distances.  So on this case only:
+#   * test_gpu_gls_fan_exact_sample holds the HIP path to "no further from exact than FAN_EXACT_SLACK x the reference's
+#     own distance" on the committed sample (tests/golden/pins/fan_exact.npz), never looser than that and never tighter
+#     than the global bar;
+#   * the all-node comparison with the C restatement uses FAN_RTOL[n] (64^3: 3e-10 = the two distances, rounded up).
+# Every other case keeps WEIGHT_RTOL.
+FAN_RTOL = {32: 1e-10, 64: 3e-10}
+FAN_EXACT_SLACK = 1.5
 
 
 def fan_rtol(n):
-    return max(WEIGHT_RTOL, FAN_PORT_VS_REFERENCE[n])
+    return max(WEIGHT_RTOL, FAN_RTOL[n])
+
+
+def load_fan_exact():
+    return np.load(os.path.join(GOLDEN_DIR, "pins", "fan_exact.npz"), allow_pickle=False)
 
 
 def flat_mesh(kind, n=5, jitter=0.12, seed=3):
