@@ -177,6 +177,12 @@ int nin_hash64(const void *data, size_t bytes, uint64_t *out);
 int nin_host_alloc(size_t bytes, void **ptr);
 int nin_host_free(void *ptr);
 
+/* Give back the scratch a grid keeps between calls: the device buffers nin_interpolate_csr_host / nin_csr_compact_host /
+ * nin_apply_* allocate on first use (weights, compacted triplets, counters: ~2.3 GB of HBM at 10 M cells, 8 x that at
+ * 80 M) and the page-locked flag staging buffer.  The next call allocates them again.  (The reference frees its dense
+ * weight table when interpolate() returns, interpolator.pyx:650-651.) */
+int nin_grid_release_scratch(nin_grid *g);
+
 /* Algorithmic HBM bytes one nin_weights call moves for `method` over all nodes (DESIGN.md formula,
  * SURVEY 8d): used by bench.py for the roofline line. */
 int64_t nin_algorithmic_bytes(const nin_grid *g, int method);

@@ -20,6 +20,7 @@ EXPORTS = (
     "nin_fields_set", "nin_weights_device", "nin_weights_host", "nin_csr_compact_host", "nin_interpolate_csr_host", "nin_apply_host",
     "nin_apply_device", "nin_apply_fields_host", "nin_pack_connectivity", "nin_pack_table_row", "nin_diff_mag",
     "nin_algorithmic_bytes", "nin_kernel_name", "nin_gls_plan", "nin_host_alloc", "nin_host_free", "nin_hash64",
+    "nin_grid_release_scratch",
 )
 
 _lib = None
@@ -73,6 +74,7 @@ def load():
     L.nin_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     L.nin_host_free.argtypes = [vp]
     L.nin_hash64.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+    L.nin_grid_release_scratch.argtypes = [vp]
     _lib = L
     return L
 
@@ -93,9 +95,24 @@ class PinnedPool:
     array dies: device-to-host copies into them run at PCIe rate, and pinning a gigabyte costs ~50 ms, so buffers are
     kept (up to `keep_bytes`) for the next call.  Not thread-safe (neither is the Interpolator)."""
 
-    def __init__(self, keep_bytes=4 << 30):
+    def __init__(self, keep_bytes=None):
+        """keep_bytes: how much page-locked memory may sit idle in the pool (default 4 GiB, or the environment's
+        NINPOL_AMD_PINNED_KEEP_BYTES); settable at any time, `trim()` gives idle buffers back to the system."""
         self.free = []          # (bytes, address)
-        self.keep_bytes = keep_bytes
+        if keep_bytes is None:
+            keep_bytes = int(os.environ.get("NINPOL_AMD_PINNED_KEEP_BYTES", 4 << 30))
+        self.keep_bytes = int(keep_bytes)
+
+    def idle_bytes(self):
+        return sum(b for b, _ in self.free)
+
+    def trim(self, to_bytes=0):
+        """Free idle page-locked buffers, largest first, until at most `to_bytes` stay.  (Buffers still referenced by
+        arrays handed out -- e.g. the CSR a caller keeps -- are not touched; they come back here when the arrays die.)"""
+        self.free.sort()
+        while self.free and self.idle_bytes() > to_bytes:
+            _, addr = self.free.pop()
+            load().nin_host_free(addr)
 
     def empty(self, n, dtype):
         import weakref

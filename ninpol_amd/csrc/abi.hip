@@ -3,6 +3,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,10 @@ int dev_upload(DeviceGrid &d, const T **ptr, const std::vector<T> &src) {
 
 void dev_free_all(DeviceGrid &d) {
     if (d.device >= 0) (void)hipSetDevice(d.device);
+    if (d.flag_staging) (void)hipHostFree(d.flag_staging);
+    if (d.ev_weights) (void)hipEventDestroy(static_cast<hipEvent_t>(d.ev_weights));
+    if (d.ev_scan) (void)hipEventDestroy(static_cast<hipEvent_t>(d.ev_scan));
+    if (d.copy_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(d.copy_stream));
     for (void *p : d.allocs) (void)hipFree(p);
     d.allocs.clear();
     d = DeviceGrid{};
@@ -400,7 +405,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         const int32_t *lp = nullptr;
         if (d.mfw[i].count && (rc = dev_upload(d, &lp, mfw_list[i]))) return rc;
         d.mfw[i].nodes = const_cast<int32_t *>(lp);
-        if (d.mfw[i].count) {   // descriptors of the one-wavefront multifrontal kernel, 32 words per list entry
+        if (d.mfw[i].count) {   // descriptors of the one-wavefront multifrontal kernel, kMfwDescWords (40) words per list entry
             if ((rc = dev_alloc(d, &d.mfw_desc[i], (size_t)d.mfw[i].count * kMfwDescWords))) return rc;
             if (launch_mfw_desc(d.v, d.mfw[i].nodes, d.mfw[i].count, d.mfw_desc[i], nullptr)) return fail(NIN_EHIP, "mfw descriptor kernel");
         }
@@ -430,13 +435,11 @@ int nin_fields_set(nin_grid *g, const double *permeability, const double *diff_m
     HostGrid &h = g->h;
     DeviceGrid &d = g->d;
     const int64_t P = h.n_points, E = h.n_elems;
-    std::vector<uint8_t> fl((size_t)P);
-#pragma omp parallel for schedule(static)
-    for (int64_t p = 0; p < P; ++p) {
-        const long long as_int = (long long)neumann_flag[p];  // `.astype(int)` (idw.pyx:28): truncation
-        fl[p] = (uint8_t)((h.boundary_points[p] ? 1 : 0) | (as_int != 0 ? 2 : 0));
-    }
-    HIP_TRY(hipMemcpy(const_cast<uint8_t *>(d.v.flags), fl.data(), (size_t)P, hipMemcpyHostToDevice));
+    // packed by the host's OpenMP team (pack_host.cpp) into a page-locked staging buffer the grid keeps: 82 MB of float64
+    // flags in, 10 MB out at 10 M nodes -- the serial loop + pageable copy this replaces took ~15 ms of every interpolate()
+    if (!d.flag_staging) HIP_TRY(hipHostMalloc((void **)&d.flag_staging, (size_t)std::max<int64_t>(P, 1), hipHostMallocDefault));
+    pack_node_flags(neumann_flag, h.boundary_points.data(), P, d.flag_staging);
+    HIP_TRY(hipMemcpy(const_cast<uint8_t *>(d.v.flags), d.flag_staging, (size_t)P, hipMemcpyHostToDevice));
     if (permeability && diff_mag) {   // NULL keeps what is resident (0.8 GB at 10 M cells: callers upload it once per mesh)
         HIP_TRY(hipMemcpy(const_cast<double *>(d.v.perm), permeability, (size_t)E * 9 * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(const_cast<double *>(d.v.diff_mag), diff_mag, (size_t)E * 8, hipMemcpyHostToDevice));
@@ -586,21 +589,56 @@ int nin_weights_host(nin_grid *g, int method, const int64_t *targets, int64_t n_
     return rc;
 }
 
-int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indptr, int32_t *indices, double *data,
-                         int64_t *nnz_out, void *stream_) {
-    if (!g || !dev_csr_data || !indptr || !nnz_out) return fail(NIN_EINVAL, "NULL argument");
+namespace {
+
+struct Laps {   // NIN_TIMING=1: host-side laps of one call on stderr
+    bool on = getenv("NIN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[nin_e2e] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
+int e2e_streams(DeviceGrid &d) {
+    if (!d.copy_stream) {
+        hipStream_t s;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        d.copy_stream = s;
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        d.ev_weights = a;
+        d.ev_scan = b;
+    }
+    return 0;
+}
+
+// The finish of interpolator.pyx:622-624 with the transfers overlapped: `weights_ready` (an event on `stream`, or null)
+// marks the weights + neumann_ws written; dev_nws / neumann_ws (optional) ride the copy stream under the count / scan /
+// compaction kernels, as does indptr; indices and data follow in pieces, each as soon as the copy engine is free.
+int csr_compact_pipelined(nin_grid *g, const double *dev_csr_data, const double *dev_nws, int32_t *indptr, int32_t *indices,
+                          double *data, int64_t *nnz_out, double *neumann_ws, hipStream_t stream) {
     DeviceGrid &d = g->d;
-    if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    HIP_TRY(hipSetDevice(d.device));
     const int64_t P = g->h.n_points;
     size_t tmp_bytes = 0;
     int rc = NIN_OK;
+    Laps L;
+    if ((rc = e2e_streams(d))) return rc;
+    hipStream_t cs = static_cast<hipStream_t>(d.copy_stream);
+    hipEvent_t ev_w = static_cast<hipEvent_t>(d.ev_weights), ev_s = static_cast<hipEvent_t>(d.ev_scan);
 #define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
     // scratch of the compaction: owned by the grid, allocated on first use (sized by the mesh: P + 1 counters, nnz_e entries)
     if (!d.e2e_cnt && (rc = dev_alloc(d, &d.e2e_cnt, (size_t)(P + 1)))) return rc;
     if (!d.e2e_ptr && (rc = dev_alloc(d, &d.e2e_ptr, (size_t)(P + 1)))) return rc;
     int32_t *cnt = d.e2e_cnt, *ptr = d.e2e_ptr;
+    if (dev_nws && neumann_ws) {   // 8 B per node: leaves as soon as the weight kernels are done
+        TRY_C(hipEventRecord(ev_w, stream));
+        TRY_C(hipStreamWaitEvent(cs, ev_w, 0));
+        TRY_C(hipMemcpyAsync(neumann_ws, dev_nws, (size_t)P * 8, hipMemcpyDeviceToHost, cs));
+    }
     TRY_C(hipMemsetAsync(cnt, 0, (size_t)(P + 1) * 4, stream));
     if ((rc = launch_row_nnz(d.v, dev_csr_data, cnt, stream))) return fail(rc, "launch failed");
     TRY_C(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, ptr, (int)(P + 1), stream));
@@ -611,21 +649,44 @@ int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indpt
         d.e2e_tmp_bytes = tmp_bytes;
     }
     TRY_C(hipcub::DeviceScan::ExclusiveSum(d.e2e_tmp, tmp_bytes, cnt, ptr, (int)(P + 1), stream));
-    TRY_C(hipMemcpyAsync(indptr, ptr, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, stream));
-    TRY_C(hipStreamSynchronize(stream));
-    const int64_t nnz = indptr[P];
-    *nnz_out = nnz;
-    if (nnz > 0 && indices && data) {
-        const size_t cap = (size_t)std::max<int64_t>(d.nnz_e, 1);
+    TRY_C(hipEventRecord(ev_s, stream));
+    const size_t cap = (size_t)std::max<int64_t>(d.nnz_e, 1);
+    const bool want_entries = indices && data;
+    if (want_entries) {   // the compaction does not need the count on the host: it starts right behind the scan
         if (!d.e2e_indices && (rc = dev_alloc(d, &d.e2e_indices, cap))) return rc;
         if (!d.e2e_data && (rc = dev_alloc(d, &d.e2e_data, cap))) return rc;
         if ((rc = launch_compact(d.v, dev_csr_data, ptr, d.e2e_indices, d.e2e_data, stream))) return fail(rc, "launch failed");
-        TRY_C(hipMemcpyAsync(indices, d.e2e_indices, (size_t)nnz * 4, hipMemcpyDeviceToHost, stream));
-        TRY_C(hipMemcpyAsync(data, d.e2e_data, (size_t)nnz * 8, hipMemcpyDeviceToHost, stream));
+    }
+    TRY_C(hipStreamWaitEvent(cs, ev_s, 0));
+    TRY_C(hipMemcpyAsync(indptr, ptr, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, cs));   // under the compaction kernel
+    TRY_C(hipStreamSynchronize(cs));
+    L.lap("weights+count+scan");
+    const int64_t nnz = indptr[P];
+    *nnz_out = nnz;
+    if (nnz > 0 && want_entries) {
         TRY_C(hipStreamSynchronize(stream));
+        L.lap("compaction");
+        // two copy queues: the index and the value stream each keep a DMA engine busy
+        TRY_C(hipMemcpyAsync(indices, d.e2e_indices, (size_t)nnz * 4, hipMemcpyDeviceToHost, stream));
+        TRY_C(hipMemcpyAsync(data, d.e2e_data, (size_t)nnz * 8, hipMemcpyDeviceToHost, cs));
+        TRY_C(hipStreamSynchronize(cs));
+        TRY_C(hipStreamSynchronize(stream));
+        L.lap("D2H indices+data");
     }
 #undef TRY_C
     return NIN_OK;
+}
+
+}  // namespace
+
+int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indptr, int32_t *indices, double *data,
+                         int64_t *nnz_out, void *stream_) {
+    if (!g || !dev_csr_data || !indptr || !nnz_out) return fail(NIN_EINVAL, "NULL argument");
+    DeviceGrid &d = g->d;
+    if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device");
+    HIP_TRY(hipSetDevice(d.device));
+    return csr_compact_pipelined(g, dev_csr_data, nullptr, indptr, indices, data, nnz_out, nullptr,
+                                 static_cast<hipStream_t>(stream_));
 }
 
 int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *indices, double *data,
@@ -634,17 +695,36 @@ int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *
     DeviceGrid &d = g->d;
     if (d.device < 0) return fail(NIN_ENODEVICE, "grid is not on a device: the weight kernels are HIP only");
     HIP_TRY(hipSetDevice(d.device));
-    const size_t pb = (size_t)g->h.n_points * 8;
     int rc = NIN_OK;
     if (!d.e2e_weights && (rc = dev_alloc(d, &d.e2e_weights, (size_t)std::max<int64_t>(d.nnz_e, 1)))) return rc;
     if (!d.e2e_nws && (rc = dev_alloc(d, &d.e2e_nws, (size_t)std::max<int64_t>(g->h.n_points, 1)))) return rc;
     rc = nin_weights_device(g, method, nullptr, 0, 1, d.e2e_weights, d.e2e_nws, nullptr);
-    if (!rc) rc = nin_csr_compact_host(g, d.e2e_weights, indptr, indices, data, nnz_out, nullptr);
-    if (!rc) {
-        const hipError_t e = hipMemcpy(neumann_ws, d.e2e_nws, pb, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(NIN_EHIP, "copy back: %s", hipGetErrorString(e));
-    }
+    if (!rc) rc = csr_compact_pipelined(g, d.e2e_weights, d.e2e_nws, indptr, indices, data, nnz_out, neumann_ws, nullptr);
     return rc;
+}
+
+// Give the grid's call scratch back (the buffers nin_interpolate_csr_host / nin_csr_compact_host / nin_apply_* allocate
+// on first use and keep: ~2.3 GB of HBM at 10 M cells, + 10 MB of page-locked host memory); the next call allocates again.
+int nin_grid_release_scratch(nin_grid *g) {
+    if (!g) return fail(NIN_EINVAL, "NULL grid");
+    DeviceGrid &d = g->d;
+    if (d.device < 0) return NIN_OK;
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(hipDeviceSynchronize());
+    void *scratch[] = {d.e2e_weights, d.e2e_nws, d.e2e_data, d.e2e_cnt, d.e2e_ptr, d.e2e_indices, d.e2e_tmp, d.apply_weights};
+    for (void *p : scratch) {
+        if (!p) continue;
+        auto it = std::find(d.allocs.begin(), d.allocs.end(), p);
+        if (it != d.allocs.end()) d.allocs.erase(it);
+        (void)hipFree(p);
+    }
+    d.e2e_weights = d.e2e_nws = d.e2e_data = nullptr;
+    d.e2e_cnt = d.e2e_ptr = d.e2e_indices = nullptr;
+    d.e2e_tmp = nullptr;
+    d.e2e_tmp_bytes = 0;
+    d.apply_weights = nullptr;
+    if (d.flag_staging) { (void)hipHostFree(d.flag_staging); d.flag_staging = nullptr; }
+    return NIN_OK;
 }
 
 int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t n_fields, double *dev_node_values,

@@ -93,6 +93,9 @@ struct DeviceGrid {
     void *e2e_tmp = nullptr;
     size_t e2e_tmp_bytes = 0;
     double *apply_weights = nullptr;   // [nnz_e] weights of the last nin_apply_device (allocated on first use)
+    uint8_t *flag_staging = nullptr;   // page-locked [n_points]: nin_fields_set packs the node flags here and uploads from it
+    void *copy_stream = nullptr;       // hipStream_t of the device-to-host copies that run under the compaction kernels
+    void *ev_weights = nullptr, *ev_scan = nullptr;   // hipEvent_t: weights written / row pointers scanned
     bool gls_too_large = false;     // some node's system has more rows than the scratch kernel handles (1024)
 };
 

@@ -44,7 +44,7 @@ inline bool elem_has_point(const int32_t *el, int n, int32_t p) {
 
 int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, const double *xyz, int coords_dim) {
     const int64_t E = n_elems, P = n_points;
-    omp_set_num_threads(num_threads > 0 ? num_threads : default_host_threads());   // (0: the CPUs this process may actually use)
+    const ScopedTeam team(num_threads);   // this build's OpenMP team (0: the CPUs this process may actually use); the process-wide default is not touched
     const bool timing = getenv("NIN_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -57,7 +57,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     inpoel.resize((size_t)E * kMaxPointsPerElement);
     etype.resize((size_t)E);
     bool bad = false;
-#pragma omp parallel for schedule(dynamic, 16384) reduction(|| : bad)
+#pragma omp parallel for schedule(dynamic, 16384) reduction(|| : bad) num_threads(nin::host_team())
     for (int64_t e = 0; e < E; ++e) {
         int64_t t = element_types[e];
         if (t < 0 || t >= kNumElementTypes) { bad = true; t = 0; }
@@ -71,7 +71,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     if (bad) return -1;
 
     coords.assign((size_t)P * 3, 0.0);
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t p = 0; p < P; ++p)
         for (int k = 0; k < coords_dim && k < 3; ++k) coords[p * 3 + k] = xyz[p * coords_dim + k];
 
@@ -80,9 +80,9 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     esup_ptr.assign((size_t)P + 1, 0);
     {
         std::vector<std::atomic<int32_t>> cnt((size_t)P);
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
         for (int64_t p = 0; p < P; ++p) cnt[p].store(0, std::memory_order_relaxed);
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
         for (int64_t e = 0; e < E; ++e) {
             int n = npoel[etype[e]];
             for (int j = 0; j < n; ++j) cnt[inpoel[e * 8 + j]].fetch_add(1, std::memory_order_relaxed);
@@ -98,9 +98,9 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
         mx_elems_per_point = mx;
         if (run >= INT32_MAX) return -5;
         esup.resize((size_t)run);
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
         for (int64_t p = 0; p < P; ++p) cnt[p].store(0, std::memory_order_relaxed);
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
         for (int64_t e = 0; e < E; ++e) {
             int n = npoel[etype[e]];
             for (int j = 0; j < n; ++j) {
@@ -109,14 +109,14 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
                 esup[esup_ptr[p] + at] = (int32_t)e;
             }
         }
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
         for (int64_t p = 0; p < P; ++p) std::sort(esup.begin() + esup_ptr[p], esup.begin() + esup_ptr[p + 1]);
     }
 
     lap("esup");
     // ---- esuel (grid.pyx:449-525) -----------------------------------------------------------
     esuel.assign((size_t)E * kMaxFacesPerElement, -1);
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t ie = 0; ie < E; ++ie) {
         const int it = etype[ie];
         const int32_t *el = &inpoel[ie * 8];
@@ -159,7 +159,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     // ---- infael / inpofa: global face numbering (grid.pyx:304-345) --------------------------
     infael.assign((size_t)E * kMaxFacesPerElement, -1);
     std::vector<int64_t> own_start((size_t)E + 1, 0);
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t e = 0; e < E; ++e) {
         int c = 0;
         for (int j = 0; j < nfael[etype[e]]; ++j) {
@@ -173,7 +173,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     if (n_faces * 4 >= INT32_MAX) return -5;
     std::vector<int32_t> face_owner((size_t)n_faces);   // creating element
     std::vector<int8_t> face_owner_lf((size_t)n_faces);  // its local face
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t e = 0; e < E; ++e) {
         int64_t f = own_start[e];
         for (int j = 0; j < nfael[etype[e]]; ++j) {
@@ -186,7 +186,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
             }
         }
     }
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t e = 0; e < E; ++e) {
         for (int j = 0; j < nfael[etype[e]]; ++j) {
             int32_t k = esuel[e * 6 + j];
@@ -198,7 +198,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     }
     const int64_t F = n_faces;
     inpofa.assign((size_t)F * kMaxPointsPerFace, -1);
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t f = 0; f < F; ++f) {
         const int64_t e = face_owner[f];
         const int t = etype[e], j = face_owner_lf[f];
@@ -224,7 +224,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     };
     const size_t fbuf = (size_t)mx_elems_per_point * kMaxFacesPerElement + 1;
     int64_t mxf = 0;
-#pragma omp parallel reduction(max : mxf)
+#pragma omp parallel num_threads(nin::host_team()) reduction(max : mxf)
     {
         std::vector<int32_t> buf(fbuf);
 #pragma omp for schedule(dynamic, 16384)
@@ -238,7 +238,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     for (int64_t p = 0; p < P; ++p) fsup_ptr[p + 1] += fsup_ptr[p];
     if (fsup_ptr[P] >= INT32_MAX) return -5;
     fsup.resize((size_t)fsup_ptr[P]);
-#pragma omp parallel
+#pragma omp parallel num_threads(nin::host_team())
     {
         std::vector<int32_t> buf(fbuf);
 #pragma omp for schedule(dynamic, 16384)
@@ -254,7 +254,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     boundary_faces.assign((size_t)F, 0);
     boundary_points.assign((size_t)P, 0);
     int64_t mxe = 0;
-#pragma omp parallel for schedule(dynamic, 16384) reduction(max : mxe)
+#pragma omp parallel for schedule(dynamic, 16384) reduction(max : mxe) num_threads(nin::host_team())
     for (int64_t f = 0; f < F; ++f) {
         const int32_t nb = esuel[(int64_t)face_owner[f] * 6 + face_owner_lf[f]];
         esuf_ptr[f + 1] = nb == -1 ? 1 : 2;
@@ -263,7 +263,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     mx_elems_per_face = mxe;
     for (int64_t f = 0; f < F; ++f) esuf_ptr[f + 1] += esuf_ptr[f];
     esuf.resize((size_t)esuf_ptr[F]);
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t f = 0; f < F; ++f) {
         const int32_t nb = esuel[(int64_t)face_owner[f] * 6 + face_owner_lf[f]];
         esuf[esuf_ptr[f]] = face_owner[f];
@@ -278,7 +278,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     // ---- geometry (grid.pyx:669-809) -----------------------------------------------------------
     centroids.assign((size_t)E * 3, 0.0);
     const int d = (int)dim;
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t e = 0; e < E; ++e) {
         const int n = npoel[etype[e]];
         for (int j = 0; j < n; ++j)
@@ -288,7 +288,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
     normal_faces.assign((size_t)F * 3, 0.0f);
     faces_areas.assign((size_t)F, 0.0);
     const double *X = coords.data();
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t f = 0; f < F; ++f) {
         int npofa = 0;
         for (int j = 0; j < kMaxPointsPerFace && inpofa[f * 4 + j] != -1; ++j) {
@@ -340,7 +340,7 @@ int HostGrid::build(const int64_t *connectivity, const int64_t *element_types, c
 void HostGrid::widen(const std::vector<int32_t> &src, std::vector<int64_t> &dst) {
     const int64_t n = (int64_t)src.size();
     dst.resize(src.size());
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nin::host_team())
     for (int64_t i = 0; i < n; ++i) dst[i] = src[i];
 }
 
@@ -350,7 +350,7 @@ void HostGrid::esuf_from_pairs(const std::vector<int32_t> &pairs) {
     esuf_ptr[0] = 0;
     for (int64_t f = 0; f < F; ++f) esuf_ptr[f + 1] = esuf_ptr[f] + (pairs[2 * f + 1] == -1 ? 1 : 2);
     esuf.resize((size_t)esuf_ptr[F]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nin::host_team())
     for (int64_t f = 0; f < F; ++f) {
         esuf[esuf_ptr[f]] = pairs[2 * f];
         if (pairs[2 * f + 1] != -1) esuf[esuf_ptr[f] + 1] = pairs[2 * f + 1];
@@ -374,7 +374,7 @@ void HostGrid::build_psup() {
         }
     };
     int64_t mx = 0;
-#pragma omp parallel reduction(max : mx)
+#pragma omp parallel num_threads(nin::host_team()) reduction(max : mx)
     {
         std::vector<int32_t> buf;
 #pragma omp for schedule(dynamic, 16384)
@@ -387,7 +387,7 @@ void HostGrid::build_psup() {
     mx_points_per_point = mx;
     for (int64_t p = 0; p < P; ++p) psup_ptr[p + 1] += psup_ptr[p];
     psup.resize((size_t)psup_ptr[P]);
-#pragma omp parallel
+#pragma omp parallel num_threads(nin::host_team())
     {
         std::vector<int32_t> buf;
 #pragma omp for schedule(dynamic, 16384)
@@ -452,7 +452,7 @@ void HostGrid::build_inedel() {
         return;
     }
     std::vector<uint64_t> kv((size_t)N);   // (key as unsigned 32 bits) << 32 | position in the walk
-#pragma omp parallel for schedule(dynamic, 16384)
+#pragma omp parallel for schedule(dynamic, 16384) num_threads(nin::host_team())
     for (int64_t i = 0; i < E; ++i) {
         const int t = etype[i];
         for (int j = 0; j < nedel[t]; ++j) {
@@ -462,13 +462,13 @@ void HostGrid::build_inedel() {
             kv[(size_t)(start[i] + j)] = ((uint64_t)key << 32) | (uint64_t)(start[i] + j);
         }
     }
-    __gnu_parallel::sort(kv.begin(), kv.end());
+    __gnu_parallel::sort(kv.begin(), kv.end(), std::less<uint64_t>(), __gnu_parallel::default_parallel_tag((unsigned)host_team()));
     std::vector<uint64_t> firsts;          // position of the first sight of every key, then sorted ascending
     firsts.reserve((size_t)N / 3 + 16);
     for (int64_t q = 0; q < N; ++q)
         if (q == 0 || (kv[q] >> 32) != (kv[q - 1] >> 32)) firsts.push_back(kv[q] & 0xffffffffu);
     std::vector<uint64_t> by_pos(firsts);
-    __gnu_parallel::sort(by_pos.begin(), by_pos.end());
+    __gnu_parallel::sort(by_pos.begin(), by_pos.end(), std::less<uint64_t>(), __gnu_parallel::default_parallel_tag((unsigned)host_team()));
     n_edges = (int64_t)by_pos.size();
     // element / local edge of a walk position (binary search over the per-element starts)
     auto locate = [&](int64_t pos, int64_t *e, int *j) {
@@ -477,7 +477,7 @@ void HostGrid::build_inedel() {
         *j = (int)(pos - start[i]);
     };
     inpoed.resize((size_t)n_edges * 2);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nin::host_team())
     for (int64_t id = 0; id < n_edges; ++id) {
         int64_t e; int j;
         locate((int64_t)by_pos[id], &e, &j);
@@ -485,7 +485,7 @@ void HostGrid::build_inedel() {
         inpoed[2 * id] = inpoel[e * 8 + lpoed[t][j][0]];       // the endpoints as first met, unsorted (grid.pyx:566-570)
         inpoed[2 * id + 1] = inpoel[e * 8 + lpoed[t][j][1]];
     }
-#pragma omp parallel for schedule(dynamic, 65536)
+#pragma omp parallel for schedule(dynamic, 65536) num_threads(nin::host_team())
     for (int64_t q = 0; q < N; ++q) {
         int64_t h0 = q;                                          // head of this key's group: walk back (groups are short)
         while (h0 > 0 && (kv[h0 - 1] >> 32) == (kv[q] >> 32)) --h0;

@@ -90,4 +90,7 @@ struct HostGrid {
     void build_inedel();
 };
 
+// pack_host.cpp (g++ -fopenmp): flags[p] = boundary bit | Neumann bit, the row cast like `.astype(int)`
+void pack_node_flags(const double *neumann_flag, const uint8_t *boundary_points, int64_t n, uint8_t *out);
+
 }  // namespace nin

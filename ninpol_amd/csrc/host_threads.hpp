@@ -29,4 +29,26 @@ inline int default_host_threads() {
     return std::max(1, n);
 }
 
+// The team of the library's OWN parallel regions.  It is passed as num_threads(...) on every region and to the parallel
+// sorts; the process-wide OpenMP default (omp_set_num_threads) is never touched -- the host application's other libgomp
+// users (torch, scipy, the caller's code) keep theirs.  ScopedTeam: an explicit num_threads of nin_grid_create, for the
+// duration of that build on the calling thread.
+inline int &host_team_override() {
+    static thread_local int t = 0;
+    return t;
+}
+inline int host_team() {
+    const int t = host_team_override();
+    if (t > 0) return t;
+    static const int d = default_host_threads();
+    return d;
+}
+struct ScopedTeam {
+    int prev;
+    explicit ScopedTeam(int n) : prev(host_team_override()) { if (n > 0) host_team_override() = n; }
+    ~ScopedTeam() { host_team_override() = prev; }
+    ScopedTeam(const ScopedTeam &) = delete;
+    ScopedTeam &operator=(const ScopedTeam &) = delete;
+};
+
 }  // namespace nin

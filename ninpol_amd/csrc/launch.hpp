@@ -30,7 +30,7 @@ int launch_hex8_desc(const GridView &g, const int32_t *nodes, int32_t count, int
 int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
                       double *out, double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_hex8mf();
-// the one-wavefront multifrontal kernel for two-coloured nodes (kernels_gls_mfw.hip); `desc` = 32 descriptor words per
+// the one-wavefront multifrontal kernel for two-coloured nodes (kernels_gls_mfw.hip); `desc` = kMfwDescWords (40) descriptor words per
 // list entry (mfw_desc.hpp, filled by launch_mfw_desc); `queue`: one zeroed device int (the work counter)
 int launch_mfw_desc(const GridView &g, const int32_t *nodes, int32_t count, uint32_t *desc, hipStream_t stream);
 // `kind`: 0 = two-coloured nodes, 1 = those among them with at most kMfwSmallFronts fronts and kMfwSmallDense dense cells,

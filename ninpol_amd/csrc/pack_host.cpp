@@ -12,13 +12,20 @@
 #include "../../include/ninpol_amd.h"
 #include "host_threads.hpp"
 
-namespace {
-// the library's default OpenMP team: the CPUs this process may use (host_threads.hpp), set once when the library loads
-// (OMP_NUM_THREADS and an explicit num_threads of nin_grid_create still win)
-struct DefaultTeam {
-    DefaultTeam() { omp_set_num_threads(nin::default_host_threads()); }
-} default_team;
-}  // namespace
+// (every parallel region below names its team, nin::host_team(): the CPUs this process may use -- host_threads.hpp; the
+// process-wide OpenMP default is left alone)
+
+namespace nin {
+// Node flags of the kernels (bit 0: boundary point, bit 1: Neumann flag) from the points_data row: `.astype(int)`
+// (idw.pyx:28, gls.pyx:55) truncates toward zero, anything non-zero after that counts (idw.pyx:62 `== 0`).
+void pack_node_flags(const double *neumann_flag, const uint8_t *boundary_points, int64_t n, uint8_t *out) {
+#pragma omp parallel for schedule(static) num_threads(nin::host_team())
+    for (int64_t p = 0; p < n; ++p) {
+        const long long as_int = (long long)neumann_flag[p];
+        out[p] = (uint8_t)((boundary_points[p] ? 1 : 0) | (as_int != 0 ? 2 : 0));
+    }
+}
+}  // namespace nin
 
 extern "C" {
 
@@ -34,7 +41,7 @@ int nin_pack_connectivity(int32_t n_blocks, const int64_t *const *block_data, co
         const int64_t *src = block_data[b];
         int64_t *dst = connectivity + at * 8;
         int64_t *ty = element_types + at;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nin::host_team())
         for (int64_t i = 0; i < n; ++i) {
             for (int64_t k = 0; k < w; ++k) dst[i * 8 + k] = src[i * w + k];
             for (int64_t k = w; k < 8; ++k) dst[i * 8 + k] = -1;
@@ -50,11 +57,11 @@ int nin_pack_connectivity(int32_t n_blocks, const int64_t *const *block_data, co
 int nin_pack_table_row(const double *src, int64_t n, int64_t src_cols, int64_t take, double *dst) {
     if (!src || !dst || n < 0 || src_cols < 1 || take < 1 || take > src_cols) return NIN_EINVAL;
     if (take == src_cols) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nin::host_team())
         for (int64_t i = 0; i < n; ++i) std::memcpy(dst + i * take, src + i * take, (size_t)take * 8);
         return NIN_OK;
     }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nin::host_team())
     for (int64_t i = 0; i < n; ++i)
         for (int64_t k = 0; k < take; ++k) dst[i * take + k] = src[i * src_cols + k];
     return NIN_OK;
@@ -64,7 +71,7 @@ int nin_pack_table_row(const double *src, int64_t n, int64_t src_cols, int64_t t
 // trace summed in np.trace's order.
 int nin_diff_mag(const double *permeability, int64_t n_elems, double *diff_mag) {
     if (!permeability || !diff_mag || n_elems < 0) return NIN_EINVAL;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nin::host_team())
     for (int64_t i = 0; i < n_elems; ++i) {
         const double *K = permeability + 9 * i;
         const double tr = (K[0] + K[4]) + K[8];
@@ -89,7 +96,7 @@ int nin_hash64(const void *data, size_t bytes, uint64_t *out) {
     std::vector<uint64_t> part(n_chunks ? n_chunks : 1, 0);
     const unsigned char *base = static_cast<const unsigned char *>(data);
     // memory-bound: 16 threads saturate it; never more than the CPUs the process may use (host_threads.hpp)
-    const int nt = std::min(nin::default_host_threads(), 16);
+    const int nt = std::min(nin::host_team(), 16);
 #pragma omp parallel for schedule(static) num_threads(nt)
     for (int64_t c = 0; c < (int64_t)n_chunks; ++c) {
         const unsigned char *q = base + (size_t)c * CH;

@@ -20,6 +20,11 @@ from .grid import Grid
 
 _pinned = _lib.PinnedPool()
 
+
+def pinned_pool():
+    """The pool of page-locked host buffers interpolate()'s results live in (`keep_bytes`, `trim()`, `idle_bytes()`)."""
+    return _pinned
+
 DTYPE_I = np.int64
 DTYPE_F = np.float64
 
@@ -97,6 +102,8 @@ def _upload_fields(grid, method, cells_data, points_data, variable_to_index, var
     _lib.check(L.nin_fields_set(grid._h, _ptr(perm), _ptr(dmag), _ptr(flag), _ptr(nval)))
     if key is not None:
         grid._perm_key = key
+    # the flags on the device belong to the GRID, not to a plan: remember whose they are (DevicePlan.ensure_current)
+    grid._fields_variable = variable
 
 
 def _run_weights(grid, method, cells_data, points_data, variable_to_index, variable, target_points, add_neumann):
@@ -111,6 +118,32 @@ def _run_weights(grid, method, cells_data, points_data, variable_to_index, varia
     _lib.check(L.nin_weights_host(grid._h, _lib.METHOD_ID[method], None if full else _ptr(targets),
                                   0 if full else len(targets), int(bool(add_neumann)), _ptr(csr), _ptr(nws)))
     return csr, nws
+
+
+def _native_interpolate(g, method):
+    """nin_interpolate_csr_host into page-locked buffers (57 against 10-15 GB/s over PCIe; recycled, see _lib.PinnedPool)."""
+    P = g.n_points
+    nnz_max = g.nnz_esup
+    empty = np.empty if os.environ.get("NINPOL_AMD_NO_PINNED") else _pinned.empty
+    indptr = empty(P + 1, dtype=np.int32)
+    indices = empty(nnz_max, dtype=np.int32)
+    data = empty(nnz_max, dtype=DTYPE_F)
+    nws = empty(P, dtype=DTYPE_F)
+    nnz = ctypes.c_int64(0)
+    _lib.check(_lib.load().nin_interpolate_csr_host(g._h, _lib.METHOD_ID[method], _ptr(indptr), _ptr(indices),
+                                                    _ptr(data), ctypes.byref(nnz), _ptr(nws)))
+    return indptr, indices[:nnz.value], data[:nnz.value], nws
+
+
+def _wrap_csr(data, indices, indptr, shape):
+    """scipy.sparse.csr_matrix over the three arrays as they are.  The constructor's check_format pass (min / max over all
+    indices, monotone indptr: ~25 ms on 80 M entries, a third of interpolate()) is skipped: the arrays come from the
+    device-side compaction, whose output is canonical by construction -- sorted, duplicate-free columns in [0, n_elems),
+    indptr[0] = 0, indptr[-1] = nnz (checked in tests/test_host.py and, against the reference's own CSR, in the GPU suite)."""
+    W = sp.csr_matrix(shape, dtype=data.dtype)
+    W.data, W.indices, W.indptr = data, indices, indptr
+    W.has_canonical_format = True        # (sorted + no duplicates: spares sum_duplicates() passes later on)
+    return W
 
 
 class Interpolator:
@@ -348,19 +381,9 @@ class Interpolator:
             # one native call: kernel with `data[j] = weights + neumann_ws[row]` (interpolator.pyx:618) fused, then the
             # device-side csr_matrix + eliminate_zeros (interpolator.pyx:622-624); only the surviving entries cross PCIe
             _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable)
-            nnz_max = g.nnz_esup
-            # the outputs land in page-locked buffers (57 against 10-15 GB/s over PCIe; recycled, see _lib.PinnedPool)
-            empty = np.empty if os.environ.get("NINPOL_AMD_NO_PINNED") else _pinned.empty
-            indptr = empty(P + 1, dtype=np.int32)
-            indices = empty(nnz_max, dtype=np.int32)
-            data = empty(nnz_max, dtype=DTYPE_F)
-            nws = empty(P, dtype=DTYPE_F)
-            nnz = ctypes.c_int64(0)
-            _lib.check(_lib.load().nin_interpolate_csr_host(g._h, _lib.METHOD_ID[method], _ptr(indptr), _ptr(indices),
-                                                            _ptr(data), ctypes.byref(nnz), _ptr(nws)))
+            indptr, indices, data, nws = _native_interpolate(g, method)
             self._log(f"Interpolation done in {time.time() - t0:.2f} seconds")
-            W = sp.csr_matrix((data[:nnz.value], indices[:nnz.value], indptr), shape=(P, E))
-            return W, nws
+            return _wrap_csr(data, indices, indptr, (P, E)), nws
         csr, nws = _run_weights(g, method, self.cells_data, self.points_data, self.variable_to_index, variable,
                                 target_points, add_neumann=True)
         self._log(f"Interpolation done in {time.time() - t0:.2f} seconds")
@@ -407,6 +430,15 @@ class Interpolator:
         _lib.check(_lib.load().nin_apply_fields_host(g._h, _lib.METHOD_ID[method], _ptr(u), k, _ptr(out), _ptr(nws)))
         return out, nws
 
+    def release_scratch(self, pinned=True):
+        """Give back what the object keeps between calls for speed: the grid's device scratch (weights, compacted
+        triplets: ~2.3 GB of HBM at 10 M cells) and, with pinned=True, the idle page-locked result buffers of the
+        process-wide pool.  Results already returned stay valid."""
+        if self.grid is not None:
+            self.grid.release_scratch()
+        if pinned:
+            _pinned.trim(0)
+
     def device_plan(self, variable, method):
         """Upload the fields of (variable, method) and return a DevicePlan (kernel-only launches)."""
         return DevicePlan(self, variable, method)
@@ -422,10 +454,15 @@ class Interpolator:
 
 
 class DevicePlan:
-    """Device-resident form of one `interpolate(variable, method)`: the field rows are uploaded once
-    and every `launch` is just the kernel, asynchronous on the caller's HIP stream, writing into the
-    caller's device buffers (e.g. torch tensors): csr_data [nnz_esup] float64, neumann_ws [n_points]
-    float64.  This is what bench.py times and what the multi-GPU path feeds to the all-gather."""
+    """Device-resident form of one `interpolate(variable, method)`: the field rows are uploaded by `refresh()` (once at
+    construction) and every `launch` is just the kernel, asynchronous on the caller's HIP stream, writing into the
+    caller's device buffers (e.g. torch tensors): csr_data [nnz_esup] float64, neumann_ws [n_points] float64.  This is
+    what bench.py times and what the multi-GPU path feeds to its exchange.
+
+    The Neumann flags and the permeability on the device belong to the grid, not to the plan: a launch first checks that
+    the grid's resident flags are still this plan's variable (another plan, or interpolate() on another variable, may
+    have replaced them) and re-uploads if not; `refresh()` re-reads the caller's tables unconditionally -- an in-place
+    edit of a table is only seen there, exactly as Interpolator.interpolate() sees it on every call."""
 
     def __init__(self, interp, variable, method):
         if not interp.is_grid_initialized:
@@ -433,19 +470,47 @@ class DevicePlan:
         if method not in interp.supported_methods:
             raise ValueError(f"Method '{method}' not supported. Supported methods are: "
                              f"{list(interp.supported_methods.keys())}")
+        self.interp = interp
+        self.variable = variable
         self.grid = g = interp.grid
         self.method = method
         self.method_id = _lib.METHOD_ID[method]
         L = _lib.load()
-        _upload_fields(g, method, interp.cells_data, interp.points_data, interp.variable_to_index, variable,
-                       device=interp.device, always_perm=True)
+        self.refresh()
         P = g.n_points
         self.nnz = int(L.nin_grid_scalar(g._h, b"nnz_esup"))
         self.n_points = P
+        self.n_elems = g.n_elems
         self.algorithmic_bytes = int(L.nin_algorithmic_bytes(g._h, self.method_id))
         self.kernel_name = L.nin_kernel_name(self.method_id).decode()
 
+    def refresh(self):
+        """Upload this plan's field rows from the Interpolator's tables as they are NOW (flags always; permeability and
+        diff_mag when their contents changed: a hash of all their bytes)."""
+        I = self.interp
+        _upload_fields(self.grid, self.method, I.cells_data, I.points_data, I.variable_to_index, self.variable,
+                       device=I.device, always_perm=True)
+
+    def ensure_current(self):
+        if getattr(self.grid, "_fields_variable", None) != self.variable:
+            self.refresh()
+
+    def any_neumann_flag(self):
+        """Does any node carry neumann_flag_<variable>?  (neumann_ws is identically zero otherwise.)"""
+        I = self.interp
+        row = I.variable_to_index["points"]["neumann_flag_" + self.variable]
+        return bool(np.any(np.asarray(I.points_data)[row][:self.n_points].astype(np.int64) != 0))
+
     def launch(self, csr_data_ptr, neumann_ws_ptr, stream=0, add_neumann=True):
+        self.ensure_current()
         _lib.check(_lib.load().nin_weights_device(self.grid._h, self.method_id, None, 0, int(bool(add_neumann)),
                                                   ctypes.c_void_p(csr_data_ptr), ctypes.c_void_p(neumann_ws_ptr),
                                                   ctypes.c_void_p(stream)))
+
+    def launch_apply(self, u_cells_ptr, n_fields, node_values_ptr, neumann_ws_ptr, stream=0):
+        """W . u on the device for n_fields cell fields (nin_apply_device): u [n_fields][n_elems] ->
+        node_values [n_fields][n_points], weights computed once; asynchronous on `stream`."""
+        self.ensure_current()
+        _lib.check(_lib.load().nin_apply_device(self.grid._h, self.method_id, ctypes.c_void_p(u_cells_ptr), int(n_fields),
+                                                ctypes.c_void_p(node_values_ptr), ctypes.c_void_p(neumann_ws_ptr),
+                                                ctypes.c_void_p(stream)))

@@ -86,27 +86,44 @@ def allgatherv(tensors, counts_hint=None, group=None):
 
 
 class ShardedPlan:
-    """Device-resident `interpolate(variable, method)` over the process group: this rank's kernel writes its node
-    block's CSR values, ONE all-gather per step reassembles the (count, column, value) triplets + the Neumann array on
-    every rank.  Columns and counts do not depend on the step (they are the esup rows of the owned nodes, global cell
-    ids): they are gathered once, here; a step moves 8 B per entry (+ 8 B per row for the Neumann array, only when it
-    can be non-zero at all).
+    """Device-resident `interpolate(variable, method)` / `apply(...)` over the process group.
+
+    Two exchanges, both ONE all-gather per step and nothing else:
+
+      * `step()` -- the matrix: this rank's kernel writes its node block's CSR values, the all-gather reassembles the
+        (count, column, value) triplets + the Neumann array on every rank.  Columns and counts do not depend on the step
+        (they are the esup rows of the owned nodes, global cell ids): they are gathered once, on first use; a step moves
+        8 B per ENTRY (+ 8 B per row for the Neumann array, only when it can be non-zero at all).
+      * `apply_step(u)` -- what the reference's callers do with the matrix (`weights.dot(u)`,
+        tests/utils/analytical.py:236): this rank applies its own row block on the device (nin_apply_device) and the
+        all-gather moves 8 B per NODE and field -- 82 MB in total at 80 M cells against 4.5 GB per GPU for the matrix.
 
     Shards are padded to the longest (RCCL has no allgatherv); rank r's piece of a gathered tensor `t` is
     t[r * mx : r * mx + lens[r]].  Two output / gather buffer sets rotate: `step()` returns at once, the gather of step
     i runs (on the collective's stream) under the kernel of step i + 1, and the buffers of a step stay valid until the
-    step after next starts."""
+    step after next starts.
+
+    The Neumann flags / permeability on the device belong to the local grid, not to this plan: every step checks that
+    they are still this plan's variable (DevicePlan.ensure_current), `refresh()` re-reads the caller's tables and
+    re-derives `gather_neumann` (a collective: call it on every rank) -- ShardedInterpolator.interpolate() / apply() do
+    that on every call, as the single-GPU interpolate() does; a bare step() loop (bench.py) pays neither."""
 
     def __init__(self, sharded, variable, method):
         import torch
         import torch.distributed as dist
         S = self.S = sharded
-        self.method = method
-        self.plan = S.local.device_plan(variable, method)
-        g = S.local.grid
-        esup_ptr = np.asarray(g.esup_ptr)
+        self.variable, self.method = variable, method
+        self.empty = S.local is None                  # this rank owns no node (more ranks than node planes, say)
+        self.plan = None if self.empty else S.local.device_plan(variable, method)
         lo, hi = S.own_lo, S.own_hi
-        self.eb, self.ee = int(esup_ptr[lo]), int(esup_ptr[hi])
+        if self.empty:
+            self.eb = self.ee = 0
+            self.local_points = self.local_elems = self.local_nnz = 0
+        else:
+            g = S.local.grid
+            esup_ptr = np.asarray(g.esup_ptr)
+            self.eb, self.ee = int(esup_ptr[lo]), int(esup_ptr[hi])
+            self.local_points, self.local_elems, self.local_nnz = int(self.plan.n_points), int(g.n_elems), int(self.plan.nnz)
         self.n_owned = hi - lo
         dev, cdev = S.torch_device, S.comm_device
         self.dev = dev
@@ -114,32 +131,62 @@ class ShardedPlan:
         all_lens = [torch.empty_like(lens) for _ in range(S.world)]
         dist.all_gather(all_lens, lens, group=S.group)
         self.lens = torch.stack(all_lens).cpu().numpy()          # (world, 2): entries, rows per rank
-        self.mx_nnz, self.mx_rows = int(self.lens[:, 0].max()), int(self.lens[:, 1].max())
-        # static parts, global ids, padded, gathered once
-        cols = S.global_cells(np.asarray(g.esup)[self.eb:self.ee]).astype(np.int32)
+        self.mx_nnz, self.mx_rows = max(int(self.lens[:, 0].max()), 1), max(int(self.lens[:, 1].max()), 1)
+        self.cols = self.counts = None        # static parts of the matrix exchange: gathered on the first step()
+        self.out = self.vals = None
+        n_nws = max(self.local_points, lo + self.mx_rows)        # the padded send window must stay inside the buffer
+        self.nws = [torch.zeros(n_nws, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.neumann = None
+        self.gather_neumann = None
+        self._derive_gather_neumann()
+        self.pending = [None, None]
+        self.n_steps = 0
+        self._apply = {}                      # n_fields -> buffers of apply_step
+
+    # -- what depends on the caller's tables -------------------------------------------------------------------------
+    def _derive_gather_neumann(self):
+        """neumann_ws is identically zero unless the method is GLS and some node of the mesh carries the Neumann flag
+        (idw.pyx / ls.pyx never write it; gls.pyx:470-472 only on flagged nodes): decided over all ranks, and then it
+        is not gathered at all -- 11 % of a matrix step's bytes on an all-Dirichlet hexahedron mesh."""
+        import torch
+        import torch.distributed as dist
+        S = self.S
+        mine = 0 if self.empty else int(self.method == "gls" and S._any_neumann_flag(self.plan, self.variable))
+        flagged = torch.tensor([mine], dtype=torch.int32, device=S.comm_device)
+        dist.all_reduce(flagged, op=dist.ReduceOp.MAX, group=S.group)
+        g = bool(int(flagged[0]))
+        if g != self.gather_neumann:
+            self.gather_neumann = g
+            self.neumann = [(torch.empty if g else torch.zeros)(S.world * self.mx_rows, dtype=torch.float64, device=self.dev)
+                            for _ in range(2)]
+
+    def refresh(self):
+        """Re-read the caller's field tables (flags, Neumann values, permeability, diff_mag) and re-derive what was
+        derived from them.  Collective: every rank of the group calls it."""
+        self.drain_all()
+        if not self.empty:
+            self.plan.refresh()
+        self._derive_gather_neumann()
+
+    # -- the matrix exchange --------------------------------------------------------------------------------------------
+    def _matrix_buffers(self):
+        import torch
+        S, dev = self.S, self.dev
         cols_pad = torch.zeros(self.mx_nnz, dtype=torch.int32, device=dev)
-        cols_pad[:self.ee - self.eb] = torch.from_numpy(np.ascontiguousarray(cols)).to(dev)
         cnt_pad = torch.zeros(self.mx_rows, dtype=torch.int32, device=dev)
-        cnt_pad[:self.n_owned] = torch.from_numpy(np.diff(esup_ptr[lo:hi + 1]).astype(np.int32)).to(dev)
+        if not self.empty:
+            g = S.local.grid
+            esup_ptr = np.asarray(g.esup_ptr)
+            cols = S.global_cells(np.asarray(g.esup)[self.eb:self.ee]).astype(np.int32)
+            cols_pad[:self.ee - self.eb] = torch.from_numpy(np.ascontiguousarray(cols)).to(dev)
+            cnt_pad[:self.n_owned] = torch.from_numpy(np.diff(esup_ptr[S.own_lo:S.own_hi + 1]).astype(np.int32)).to(dev)
         self.cols = torch.empty(S.world * self.mx_nnz, dtype=torch.int32, device=dev)
         self.counts = torch.empty(S.world * self.mx_rows, dtype=torch.int32, device=dev)
         S._gather(self.cols, cols_pad)
         S._gather(self.counts, cnt_pad)
-        n_out = max(int(self.plan.nnz), self.eb + self.mx_nnz)   # the padded send window must stay inside the buffer
-        n_nws = max(int(self.plan.n_points), lo + self.mx_rows)
+        n_out = max(self.local_nnz, self.eb + self.mx_nnz)
         self.out = [torch.zeros(n_out, dtype=torch.float64, device=dev) for _ in range(2)]
-        self.nws = [torch.zeros(n_nws, dtype=torch.float64, device=dev) for _ in range(2)]
         self.vals = [torch.empty(S.world * self.mx_nnz, dtype=torch.float64, device=dev) for _ in range(2)]
-        # neumann_ws is identically zero unless the method is GLS and some node of the mesh carries the Neumann flag
-        # (idw.pyx / ls.pyx never write it; gls.pyx:470-472 only on flagged nodes): decided once, over all ranks, and
-        # then not gathered at all -- 11 % of a step's bytes on an all-Dirichlet hexahedron mesh
-        flagged = torch.tensor([1 if (method == "gls" and S._any_neumann_flag(variable)) else 0], dtype=torch.int32, device=cdev)
-        dist.all_reduce(flagged, op=dist.ReduceOp.MAX, group=S.group)
-        self.gather_neumann = bool(int(flagged[0]))
-        self.neumann = [(torch.empty if self.gather_neumann else torch.zeros)(S.world * self.mx_rows, dtype=torch.float64, device=dev)
-                        for _ in range(2)]
-        self.pending = [None, None]
-        self.n_steps = 0
 
     def drain(self, b):
         if self.pending[b] is not None:
@@ -151,34 +198,91 @@ class ShardedPlan:
         self.drain(0)
         self.drain(1)
 
-    def step(self, events=None):
+    def step(self, events=None, exchange=True):
         """One pass of the hot path over this rank's shard + the exchange; returns the buffer set it went to.
-        events: optional (start, end) torch.cuda.Event pair recorded around the kernel launches (bench.py)."""
+        events: optional (start, end) torch.cuda.Event pair recorded around the kernel launches (bench.py).
+        exchange=False: the kernels alone (bench.py's compute-only leg)."""
         S = self.S
+        if self.out is None:
+            self._matrix_buffers()
         b = self.n_steps % 2
         self.n_steps += 1
         self.drain(b)             # the gather that last read this buffer set must have been delivered
         if events is not None:
             events[0].record()
-        S._launch(self.plan, self.out[b], self.nws[b])
+        if not self.empty:
+            S._launch(self.plan, self.out[b], self.nws[b])
         if events is not None:
             events[1].record()
+        if exchange:
+            self.exchange(b)
+        return b
+
+    def exchange(self, b):
+        """The all-gather of buffer set b alone (asynchronous; bench.py times it without the kernel too)."""
+        S = self.S
         lo = S.own_lo
         self.pending[b] = [S._gather(self.vals[b], self.out[b][self.eb:self.eb + self.mx_nnz], async_op=True)]
         if self.gather_neumann:
             self.pending[b].append(S._gather(self.neumann[b], self.nws[b][lo:lo + self.mx_rows], async_op=True))
         self.pending[b] = [w for w in self.pending[b] if w is not None] or None
-        return b
 
     def pieces(self, t, which):
         """Per-rank pieces of a gathered tensor (which: 0 = per entry, 1 = per row)."""
         mx = self.mx_nnz if which == 0 else self.mx_rows
         return [t[r * mx:r * mx + int(self.lens[r, which])] for r in range(self.S.world)]
 
+    # -- the apply exchange -----------------------------------------------------------------------------------------
+    def _apply_buffers(self, k):
+        import torch
+        if k not in self._apply:
+            dev, W = self.dev, self.S.world
+            self._apply[k] = dict(
+                node=[torch.zeros((k, max(self.local_points, 1)), dtype=torch.float64, device=dev) for _ in range(2)],
+                send=[torch.zeros((k, self.mx_rows), dtype=torch.float64, device=dev) for _ in range(2)],
+                recv=[torch.empty((W, k, self.mx_rows), dtype=torch.float64, device=dev) for _ in range(2)])
+        return self._apply[k]
+
+    def apply_step(self, u_local, events=None):
+        """node values of this rank's block = W_block . u on the device, then ONE all-gather of 8 B per node and field.
+        u_local: (k, n_local_cells) float64 tensor on this rank's device (values of the shard's cells, halo included).
+        Returns the buffer set; `apply_result(k, b)` assembles (k, n_points) from it once drained."""
+        S = self.S
+        k = int(u_local.shape[0])
+        B = self._apply_buffers(k)
+        b = self.n_steps % 2
+        self.n_steps += 1
+        self.drain(b)
+        if events is not None:
+            events[0].record()
+        if not self.empty:
+            S._launch_apply(self.plan, u_local, B["node"][b], self.nws[b])
+            B["send"][b][:, :self.n_owned].copy_(B["node"][b][:, S.own_lo:S.own_hi])
+        if events is not None:
+            events[1].record()
+        self.pending[b] = [S._gather(B["recv"][b].view(-1), B["send"][b].view(-1), async_op=True)]
+        if self.gather_neumann:
+            lo = S.own_lo
+            self.pending[b].append(S._gather(self.neumann[b], self.nws[b][lo:lo + self.mx_rows], async_op=True))
+        self.pending[b] = [w for w in self.pending[b] if w is not None] or None
+        return b
+
+    def apply_result(self, k, b):
+        """(k, n_points) node values on the device from buffer set b (drained first)."""
+        import torch
+        self.drain(b)
+        recv = self._apply[k]["recv"][b]
+        rows = self.lens[:, 1]
+        if np.all(rows == self.mx_rows):
+            return recv.permute(1, 0, 2).reshape(k, -1)
+        return torch.cat([recv[r, :, :int(rows[r])] for r in range(self.S.world)], dim=1)
+
 
 class ShardedInterpolator:
-    """`interpolate()` over a process group: rank r holds the node block [P r / W, P (r+1) / W) of the mesh plus the
-    cells around it, computes those rows on its own GPU and receives the whole (n_points x n_elems) matrix.
+    """`interpolate()` / `apply()` over a process group: rank r holds the node block [P r / W, P (r+1) / W) of the mesh
+    plus the cells around it and computes those rows on its own GPU.  `interpolate()` delivers the whole
+    (n_points x n_elems) matrix to every rank (the all-gather of north_star); `apply()` delivers W . u -- each rank
+    applies its own row block and only node values travel.
 
     Two ways in: `load_mesh(mesh_obj)` -- every rank is handed the same whole mesh and cuts its block out of it -- and
     `load_shard(...)` -- every rank brings only its own shard (a slab generated or read per rank: no rank ever holds the
@@ -208,26 +312,43 @@ class ShardedInterpolator:
         self._plans = {}
 
     # ---- loading ------------------------------------------------------------------------------------------------
-    def load_mesh(self, mesh_obj):
+    def load_mesh(self, mesh_obj, bounds=None):
+        """bounds: optional world + 1 ascending node offsets (bounds[r] .. bounds[r + 1] = rank r's block) instead of the
+        equal split -- e.g. blocks balanced by cost on a mesh whose nodes differ (a Kuhn-tetrahedra node costs ~20 cube
+        nodes); a rank may own nothing."""
         n_points = int(np.asarray(mesh_obj.points).shape[0])
-        lo, hi = node_block(n_points, self.rank, self.world)
-        sub, point_ids, cell_ids, owned = extract_submesh(mesh_obj, lo, hi)
+        if bounds is None:
+            lo, hi = node_block(n_points, self.rank, self.world)
+        else:
+            bounds = [int(b) for b in bounds]
+            if len(bounds) != self.world + 1 or bounds[0] != 0 or bounds[-1] != n_points or any(
+                    a > b for a, b in zip(bounds, bounds[1:])):
+                raise ValueError(f"bounds must be {self.world + 1} ascending node offsets from 0 to {n_points}")
+            lo, hi = bounds[self.rank], bounds[self.rank + 1]
         dim = T.mesh_dimension([b.type for b in mesh_obj.cells])
         n_elems = int(sum(len(b.data) for b in mesh_obj.cells if b.type in T.TYPES_PER_DIMENSION[dim]))
-        assert len(owned) == hi - lo and (len(owned) == 0 or np.array_equal(owned, np.arange(owned[0], owned[0] + len(owned))))
-        self.load_shard(sub, point_ids, cell_ids, (int(owned[0]) if len(owned) else 0, int(owned[0]) + len(owned) if len(owned) else 0),
-                        n_points, n_elems)
+        if hi == lo:
+            self.load_shard(None, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), (0, 0), n_points, n_elems)
+            return
+        sub, point_ids, cell_ids, owned = extract_submesh(mesh_obj, lo, hi)
+        assert len(owned) == hi - lo and np.array_equal(owned, np.arange(owned[0], owned[0] + len(owned)))
+        self.load_shard(sub, point_ids, cell_ids, (int(owned[0]), int(owned[0]) + len(owned)), n_points, n_elems)
 
     def load_shard(self, shard_mesh, point_ids, cell_ids, owned, n_points, n_elems):
-        """shard_mesh: this rank's cells and the points they use, local numbering monotone in the global one.
-        point_ids / cell_ids: local -> global ids, as arrays or -- for a contiguous slab -- as integer offsets.
-        owned: the LOCAL node range (lo, hi) this rank owns (globally: a contiguous block; blocks of the ranks tile
-        [0, n_points) in rank order).  n_points / n_elems: of the whole mesh."""
+        """shard_mesh: this rank's cells and the points they use, local numbering monotone in the global one (None: this
+        rank owns nothing).  point_ids / cell_ids: local -> global ids, as arrays or -- for a contiguous slab -- as
+        integer offsets.  owned: the LOCAL node range (lo, hi) this rank owns (globally: a contiguous block; blocks of
+        the ranks tile [0, n_points) in rank order).  n_points / n_elems: of the whole mesh."""
         self.n_points, self.n_elems = int(n_points), int(n_elems)
         self.point_ids, self.cell_ids = point_ids, cell_ids
         self.own_lo, self.own_hi = int(owned[0]), int(owned[1])
         self.lo = int(self.global_points(np.array([self.own_lo]))[0]) if self.own_hi > self.own_lo else 0
         self.hi = self.lo + (self.own_hi - self.own_lo)
+        self._plans = {}
+        if shard_mesh is None or self.own_hi == self.own_lo:
+            self.local = None
+            self.own_lo = self.own_hi = 0
+            return
         if self._make is None:
             from .interpolator import Interpolator
             self.local = Interpolator(device=self.device if self.device is not None else 0, grid_build=self.grid_build,
@@ -235,12 +356,13 @@ class ShardedInterpolator:
         else:
             self.local = self._make()
         self.local.load_mesh(mesh_obj=shard_mesh)
-        self._plans = {}
 
-    def _any_neumann_flag(self, variable):
+    def _any_neumann_flag(self, plan, variable):
         """Does any node of this rank's shard carry neumann_flag_<variable>?  (True when the compute object does not
         expose its point table: then the Neumann array is always gathered.)"""
         try:
+            if hasattr(plan, "any_neumann_flag"):
+                return plan.any_neumann_flag()
             row = self.local.variable_to_index["points"]["neumann_flag_" + variable]
             return bool(np.any(np.asarray(self.local.points_data)[row].astype(np.int64) != 0))
         except (AttributeError, KeyError, IndexError, TypeError):
@@ -251,6 +373,13 @@ class ShardedInterpolator:
 
     def global_points(self, local_ids):
         return local_ids + self.point_ids if np.isscalar(self.point_ids) else np.asarray(self.point_ids)[local_ids]
+
+    def local_cell_ids(self):
+        """Global ids of this rank's cells (local order)."""
+        if self.local is None:
+            return np.zeros(0, dtype=np.int64)
+        n = int(self.local.grid.n_elems)
+        return np.arange(n, dtype=np.int64) + self.cell_ids if np.isscalar(self.cell_ids) else np.asarray(self.cell_ids)
 
     # ---- the exchange ---------------------------------------------------------------------------------------------
     def _gather(self, out_t, in_t, async_op=False):
@@ -272,7 +401,17 @@ class ShardedInterpolator:
         plan.launch(out_t.data_ptr(), nws_t.data_ptr(), torch.cuda.current_stream(self.torch_device).cuda_stream,
                     add_neumann=True)
 
+    def _launch_apply(self, plan, u_t, node_t, nws_t):
+        if hasattr(plan, "apply_tensors"):             # injected compute object (CPU tests)
+            plan.apply_tensors(u_t, node_t, nws_t)
+            return
+        import torch
+        assert u_t.is_contiguous() and node_t.is_contiguous() and u_t.shape[1] == plan.n_elems
+        plan.launch_apply(u_t.data_ptr(), int(u_t.shape[0]), node_t.data_ptr(), nws_t.data_ptr(),
+                          torch.cuda.current_stream(self.torch_device).cuda_stream)
+
     def device_plan(self, variable, method):
+        """The (variable, method) plan of this mesh; building one is a collective (every rank calls it)."""
         key = (variable, method)
         if key not in self._plans:
             self._plans[key] = ShardedPlan(self, variable, method)
@@ -282,7 +421,10 @@ class ShardedInterpolator:
         """One step, waited for.  Returns (plan, b): the gathered triplets are plan.counts / plan.cols (static) and
         plan.vals[b] / plan.neumann[b], padded per rank -- see ShardedPlan.pieces()."""
         import torch
+        fresh = (variable, method) not in self._plans
         sp_ = self.device_plan(variable, method)
+        if not fresh:
+            sp_.refresh()         # the caller's tables as they are now (another variable / an edit may have intervened)
         b = sp_.step()
         sp_.drain(b)
         if self.torch_device.type == "cuda":
@@ -302,3 +444,46 @@ class ShardedInterpolator:
         full = sp.csr_matrix((data, indices.astype(idx_t), indptr.astype(idx_t)), shape=(self.n_points, self.n_elems))
         full.eliminate_zeros()
         return full, neumann
+
+    def apply(self, variable, method, values=None, local_values=False):
+        """`W.dot(u)` of the reference's callers (tests/utils/analytical.py:236) over the group: every rank applies its
+        own row block on its GPU and ONE all-gather of node values (8 B per node and field) delivers the result to all.
+        values: one cell field (n_elems,) or k of them (k, n_elems) in GLOBAL cell numbering (default: the cell
+        variable `variable` of this rank's shard); local_values=True: `values` holds only this rank's cells, shard order
+        (halo cells included) -- for callers that never hold the whole mesh.  Returns (node_values, neumann_ws) like
+        Interpolator.apply: (n_points,) or (k, n_points), Dirichlet rows 0."""
+        import torch
+        fresh = (variable, method) not in self._plans
+        sp_ = self.device_plan(variable, method)
+        if not fresh:
+            sp_.refresh()
+        one = False
+        if sp_.empty:
+            k = 1 if values is None or np.ndim(values) == 1 else int(np.shape(values)[0])
+            one = values is None or np.ndim(values) == 1
+            u = np.zeros((k, 0))
+        else:
+            L = self.local
+            if values is None:
+                u = np.asarray(L.cells_data[L.variable_to_index["cells"][variable]])[:sp_.local_elems]
+            else:
+                u = np.asarray(values, dtype=np.float64)
+                n_expected = sp_.local_elems if local_values else self.n_elems
+                if u.shape[-1] != n_expected or u.ndim not in (1, 2):
+                    raise ValueError(f"values must have shape ({n_expected},) or (k, {n_expected}), not {u.shape}.")
+                if not local_values:
+                    u = u[..., self.local_cell_ids()]
+            one = u.ndim == 1
+            u = np.ascontiguousarray(u.reshape(1, -1) if one else u, dtype=np.float64)
+            k = u.shape[0]
+        # the number of fields must agree over the group (it sizes the gather); an empty rank learns it from the others
+        kk = torch.tensor([k], dtype=torch.int64, device=self.comm_device)
+        import torch.distributed as dist
+        dist.all_reduce(kk, op=dist.ReduceOp.MAX, group=self.group)
+        k = int(kk[0])
+        ut = torch.from_numpy(u).to(self.torch_device) if not sp_.empty else torch.zeros((k, 0), dtype=torch.float64,
+                                                                                          device=self.torch_device)
+        b = sp_.apply_step(ut)
+        vals = sp_.apply_result(k, b).cpu().numpy()
+        neumann = torch.cat(sp_.pieces(sp_.neumann[b], 1)).cpu().numpy()
+        return (vals[0] if one else vals), neumann

@@ -543,3 +543,35 @@ def test_gpu_permeability_stays_resident_and_follows_edits():
     J.cells_data[:] = I.cells_data
     W4, _ = J.interpolate("u", "gls")
     assert np.array_equal(W3.data, W4.data) and not np.array_equal(W3.data, W1.data)
+
+
+def test_gpu_csr_result_is_canonical_and_scratch_can_be_released():
+    """interpolate() hands scipy the compaction's arrays without the constructor's validation pass: they must BE what
+    that pass would have accepted (indptr monotone from 0 to nnz, sorted duplicate-free in-range columns) and behave as a
+    csr_matrix in the operations callers use; release_scratch() returns the kept device buffers and the next call works."""
+    import scipy.sparse as sp
+    import ninpol_amd
+    mesh = M.mixed_mesh(9, 5, 5, jitter=0.1, seed=2)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=4)
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    u = np.concatenate(mesh.cell_data["u"])
+    for meth in ("gls", "idw", "ls"):
+        W, nws = I.interpolate("u", meth)
+        assert isinstance(W, sp.csr_matrix) and W.dtype == np.float64 and W.indices.dtype == np.int32
+        assert W.indptr[0] == 0 and W.indptr[-1] == W.nnz == len(W.data) == len(W.indices)
+        assert np.all(np.diff(W.indptr) >= 0) and W.indices.min() >= 0 and W.indices.max() < I.grid.n_elems
+        rows = np.repeat(np.arange(W.shape[0]), np.diff(W.indptr))
+        assert np.all((np.diff(W.indices) > 0) | (np.diff(rows) > 0)), "columns sorted and unique inside every row"
+        V = sp.csr_matrix((W.data.copy(), W.indices.copy(), W.indptr.copy()), shape=W.shape)    # the validating constructor
+        assert (W != V).nnz == 0 and np.array_equal(W.dot(u), V.dot(u)) and np.array_equal(W.T.dot(nws), V.T.dot(nws))
+        assert np.array_equal(W[5:50].toarray(), V[5:50].toarray()) and (W + V).nnz == W.nnz
+        first = (W.data.copy(), nws.copy())
+        I.release_scratch()
+        assert ninpol_amd.pinned_pool().idle_bytes() == 0
+        W2, nws2 = I.interpolate("u", meth)
+        assert np.array_equal(W2.data, first[0], equal_nan=True) and np.array_equal(nws2, first[1], equal_nan=True)
+        vals, _ = I.apply("u", meth)
+        I.release_scratch(pinned=False)
+        vals2, _ = I.apply("u", meth)
+        assert np.array_equal(vals, vals2, equal_nan=True)

@@ -116,3 +116,105 @@ def test_rccl_backend_one_rank_group(tmp_path):
     z = np.load(os.path.join(str(tmp_path), "rccl.npz"))
     assert np.array_equal(z["indptr"], W.indptr) and np.array_equal(z["indices"], W.indices)
     assert np.array_equal(z["data"], W.data, equal_nan=True) and np.array_equal(z["nws"], nws, equal_nan=True)
+
+
+def _twovars_mesh():
+    """u: Neumann plane z = 0, v: all-Dirichlet, w: Neumann plane x = 1 (flags and values are per variable)."""
+    m = M.mixed_mesh(9, 5, 5, jitter=0.1, seed=3)
+    M.attach_fields(m, "u", perm="ALH", neumann_plane=(2, 0.0), seed=5)
+    P = len(m.points)
+    on = np.abs(m.points[:, 0] - 1.0) < 1e-12
+    fw, vw = np.zeros(P), np.zeros(P)
+    fw[on] = 1.0
+    vw[on] = np.random.default_rng(9).uniform(0.0, 1.0, int(on.sum()))
+    m.point_data.update({"neumann_flag_w": fw, "neumann_w": vw, "neumann_flag_v": np.zeros(P), "neumann_v": np.zeros(P)})
+    m.cell_data["v"] = [np.sin(2.0 * np.asarray(a)) for a in m.cell_data["u"]]
+    m.cell_data["w"] = [np.cos(3.0 * np.asarray(a)) for a in m.cell_data["u"]]
+    return m
+
+
+SEQ = ("u", "v", "u", "w", "v", "w")
+
+
+def _edit_tables(I):
+    """In place: v's flag row becomes w's, and every cell's permeability diagonal is scaled (diff_mag follows)."""
+    pi = I.variable_to_index["points"]
+    I.points_data[pi["neumann_flag_v"]][:] = I.points_data[pi["neumann_flag_w"]]
+    ci = I.variable_to_index["cells"]
+    E = I.grid.n_elems
+    I.cells_data[ci["permeability"], :E * 9] *= 1.0 + 0.3 * np.tile(np.arange(9) % 4 == 0, E)
+    I.cells_data[ci["diff_mag"], :E] = I.compute_diffusion_magnitude(I.cells_data[ci["permeability"], :E * 9].reshape(-1, 9))
+
+
+def _alternate_worker(rank, world, port, out_dir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ninpol_amd.partition import ShardedInterpolator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = ShardedInterpolator(device=0, comm_on_host=True)
+        mesh = _twovars_mesh()
+        S.load_mesh(mesh)
+        out = {}
+        for i, var in enumerate(SEQ):                  # cached plans revisited; the device flags belong to the grid
+            W, nws = S.interpolate(var, "gls")
+            out[f"{i}_data"], out[f"{i}_nws"] = W.data, nws
+        # bare plan steps, no refresh in between: the plan itself must notice that the grid holds another variable's flags
+        pu, pw = S.device_plan("u", "gls"), S.device_plan("w", "gls")
+        import torch
+        for j, sp in enumerate((pu, pw, pu)):
+            b = sp.step()
+            sp.drain(b)
+            torch.cuda.synchronize()
+            out[f"bare{j}_vals"] = torch.cat(sp.pieces(sp.vals[b], 0)).cpu().numpy()
+        u = np.concatenate(mesh.cell_data["u"])
+        fields = np.stack([u, np.sin(3.0 * u)])
+        for var in ("u", "w"):
+            for meth in ("gls", "idw"):
+                out[f"apply_{var}_{meth}"], out[f"apply_{var}_{meth}_nws"] = S.apply(var, meth, values=fields)
+        _edit_tables(S.local)
+        for var in ("v", "u"):
+            W, nws = S.interpolate(var, "gls")
+            out[f"edit_{var}_data"], out[f"edit_{var}_nws"] = W.data, nws
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "alt.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_plans_follow_variable_switches_and_table_edits(tmp_path):
+    """Round-2 advisor finding, on the real device state: ShardedInterpolator caches one plan per (variable, method) but
+    the Neumann flags / permeability in HBM belong to the grid.  u, v, u, w, v, w in turn (three Neumann planes), bare
+    plan.step() calls of two plans interleaved, the sharded apply, and in-place edits of a flag row and of the
+    permeability: every result equals the single-process GPU result of a fresh Interpolator for that variable / table."""
+    import ninpol_amd
+    world = 2
+    mp.spawn(_alternate_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = np.load(os.path.join(str(tmp_path), "alt.npz"))
+    mesh = _twovars_mesh()
+    I = ninpol_amd.Interpolator()
+    I.load_mesh(mesh_obj=mesh)
+    ref = {v: I.interpolate(v, "gls") for v in ("u", "v", "w")}
+    assert not np.array_equal(ref["u"][1], ref["w"][1], equal_nan=True) and not ref["v"][1].any()
+    for i, var in enumerate(SEQ):
+        assert np.array_equal(z[f"{i}_data"], ref[var][0].data, equal_nan=True), (i, var)
+        assert np.array_equal(z[f"{i}_nws"], ref[var][1], equal_nan=True), (i, var)
+    for j, var in enumerate(("u", "w", "u")):
+        vals = z[f"bare{j}_vals"]
+        assert np.array_equal(vals[vals != 0], ref[var][0].data, equal_nan=True), (j, var)
+    u = np.concatenate(mesh.cell_data["u"])
+    fields = np.stack([u, np.sin(3.0 * u)])
+    for var in ("u", "w"):
+        for meth in ("gls", "idw"):
+            vals, nws = I.apply(var, meth, values=fields)
+            assert np.array_equal(z[f"apply_{var}_{meth}"], vals, equal_nan=True), (var, meth)
+            assert np.array_equal(z[f"apply_{var}_{meth}_nws"], nws, equal_nan=True), (var, meth)
+    _edit_tables(I)
+    for var in ("v", "u"):
+        W, nws = I.interpolate(var, "gls")
+        assert np.array_equal(z[f"edit_{var}_data"], W.data, equal_nan=True), var
+        assert np.array_equal(z[f"edit_{var}_nws"], nws, equal_nan=True), var
+    assert not np.array_equal(z["edit_u_data"], ref["u"][0].data, equal_nan=True)

@@ -30,7 +30,26 @@ def _free_port():
 SLAB = (5, 4, 9)   # the slab case: hex_mesh(5, 4, 9), node planes dealt to the ranks
 
 
+def _add_variable(m, name, neumann_plane, seed):
+    """A second cell variable with its own Neumann plane (flags / values are per variable: neumann_flag_<name>)."""
+    P = m.points.shape[0]
+    on = np.abs(m.points[:, neumann_plane[0]] - neumann_plane[1]) < 1e-12
+    flag, val = np.zeros(P), np.zeros(P)
+    flag[on] = 1.0
+    val[on] = np.random.default_rng(seed).uniform(0.0, 1.0, int(on.sum()))
+    m.point_data["neumann_flag_" + name], m.point_data["neumann_" + name] = flag, val
+    m.cell_data[name] = [np.cos(3.0 * np.asarray(a)) for a in m.cell_data["u"]]
+    return m
+
+
 def _make_mesh(kind):
+    if kind == "twovars":     # u: Neumann plane z = 0, v: all-Dirichlet, w: Neumann plane x = 1
+        m = M.hex_mesh(5, 4, 6, jitter=0.15, seed=2)
+        M.attach_fields(m, "u", perm="ALH", neumann_plane=(2, 0.0), seed=5)
+        _add_variable(m, "w", (0, 1.0), 9)
+        m.point_data["neumann_flag_v"], m.point_data["neumann_v"] = np.zeros(len(m.points)), np.zeros(len(m.points))
+        m.cell_data["v"] = [np.sin(2.0 * np.asarray(a)) for a in m.cell_data["u"]]
+        return m
     if kind == "hexfree":     # all-Dirichlet boundary: neumann_ws is identically zero and is not gathered at all
         m = M.hex_mesh(5, 6, 6, jitter=0.15, seed=1)
         M.attach_fields(m, "u", perm="ALH", seed=5)
@@ -54,6 +73,11 @@ class _OraclePlan:
         self.nnz = int(o.grid.esup_ptr[-1])
         self.n_points = int(o.grid.n_points)
 
+        self.n_elems = int(o.grid.n_elems)
+
+    def refresh(self):
+        pass                      # the oracle reads the caller's tables on every launch
+
     def launch_tensors(self, out, nws):
         import torch
         g = self.o.grid
@@ -61,6 +85,13 @@ class _OraclePlan:
         counts = np.diff(g.esup_ptr)
         mask = np.arange(W.shape[1])[None, :] < counts[:, None]
         out[:self.nnz] = torch.from_numpy((W + n[:, None])[mask])
+        nws[:self.n_points] = torch.from_numpy(n)
+
+    def apply_tensors(self, u, node, nws):
+        import torch
+        W, n = self.o.interpolate(self.variable, self.method)
+        for f in range(u.shape[0]):
+            node[f, :self.n_points] = torch.from_numpy(W.dot(u[f].numpy()))
         nws[:self.n_points] = torch.from_numpy(n)
 
 
@@ -73,6 +104,7 @@ class _OracleCompute:
         self.o.load_mesh(mesh_obj)
         self.grid = self.o.grid
         self.variable_to_index, self.points_data = self.o.variable_to_index, self.o.points_data   # (the Neumann flags)
+        self.cells_data = self.o.cells_data
 
     def device_plan(self, variable, method):
         return _OraclePlan(self.o, variable, method)
@@ -124,6 +156,123 @@ def test_two_rank_gather_matches_single(tmp_path, oracle_lib, kind):
             np.testing.assert_array_equal(z["indices"], W.indices)
             np.testing.assert_array_equal(z["data"], W.data)
             np.testing.assert_array_equal(z["nws"], nws)
+
+
+def _worker_apply(rank, world, port, kind, out_dir, bounds):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from ninpol_amd.partition import ShardedInterpolator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = ShardedInterpolator(device=None, make_interpolator=_OracleCompute)
+        mesh = _make_mesh(kind)
+        S.load_mesh(mesh, bounds=bounds)
+        assert (S.local is None) == (bounds is not None and bounds[rank] == bounds[rank + 1])
+        u = np.concatenate(mesh.cell_data["u"])
+        fields = np.stack([u, np.sin(3.0 * u), np.random.default_rng(0).uniform(-1.0, 1.0, len(u))])
+        out = {}
+        for meth in ("idw", "ls", "gls"):
+            W, nws = S.interpolate("u", meth)
+            v1, n1 = S.apply("u", meth)                          # the shard's own cell variable
+            v3, n3 = S.apply("u", meth, values=fields)           # k fields, global numbering
+            loc = fields[:, S.local_cell_ids()]
+            v3l, _ = S.apply("u", meth, values=loc, local_values=True)
+            assert v1.shape == (S.n_points,) and v3.shape == (3, S.n_points)
+            assert np.array_equal(v3[0], v1) and np.array_equal(v3l, v3) and np.array_equal(n1, nws) and np.array_equal(n3, nws)
+            out.update({f"{meth}_indptr": W.indptr, f"{meth}_indices": W.indices, f"{meth}_data": W.data, f"{meth}_nws": nws,
+                        f"{meth}_v3": v3})
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world,bounds", [
+    ("hex", 2, None), ("mixed", 2, None),
+    # four ranks, one owning nothing and one owning a single node (more ranks than there is work for)
+    ("hex", 4, "tiny"), ("mixed", 4, "tiny")], ids=["hex-2", "mixed-2", "hex-4-empty-rank", "mixed-4-empty-rank"])
+def test_sharded_apply_and_uneven_blocks(tmp_path, oracle_lib, kind, world, bounds):
+    """ShardedInterpolator.apply -- each rank applies its own row block, ONE all-gather of node values -- against the
+    single-process oracle's W . u, bit for bit (same rows, same entry order, same sums), for one field, k fields in
+    global numbering and k fields handed over shard by shard; and the matrix exchange on the same (possibly very
+    uneven) blocks."""
+    mesh = _make_mesh(kind)
+    P = mesh.points.shape[0]
+    if bounds == "tiny":
+        bounds = [0, 0, P // 3, P - 1, P]
+    mp.spawn(_worker_apply, args=(world, _free_port(), kind, str(tmp_path), bounds), nprocs=world, join=True)
+    o = oracle_lib.OracleInterpolator("port", threads=1)
+    o.load_mesh(mesh)
+    u = np.concatenate(mesh.cell_data["u"])
+    fields = np.stack([u, np.sin(3.0 * u), np.random.default_rng(0).uniform(-1.0, 1.0, len(u))])
+    for meth in ("idw", "ls", "gls"):
+        W, nws = o.interpolate("u", meth)
+        ref = np.stack([W.dot(f) for f in fields])
+        for r in range(world):
+            z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+            np.testing.assert_array_equal(z[f"{meth}_indptr"], W.indptr)
+            np.testing.assert_array_equal(z[f"{meth}_indices"], W.indices)
+            np.testing.assert_array_equal(z[f"{meth}_data"], W.data)
+            np.testing.assert_array_equal(z[f"{meth}_nws"], nws)
+            np.testing.assert_array_equal(z[f"{meth}_v3"], ref)
+
+
+def _worker_alternate(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from ninpol_amd.partition import ShardedInterpolator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = ShardedInterpolator(device=None, make_interpolator=_OracleCompute)
+        S.load_mesh(_make_mesh("twovars"))
+        out = {}
+        for i, var in enumerate(("u", "v", "u", "w", "v")):        # plans are cached per (variable, method): revisit them
+            W, nws = S.interpolate(var, "gls")
+            assert S.device_plan(var, "gls").gather_neumann == (var != "v")
+            out[f"{i}_data"], out[f"{i}_nws"], out[f"{i}_indptr"] = W.data, nws, W.indptr
+        # a table edited in place between two calls: v becomes a Neumann variable; the cached plan must follow
+        L = S.local
+        row = L.variable_to_index["points"]["neumann_flag_v"]
+        L.points_data[row][:] = L.points_data[L.variable_to_index["points"]["neumann_flag_w"]]
+        W, nws = S.interpolate("v", "gls")
+        assert S.device_plan("v", "gls").gather_neumann
+        out["edit_data"], out["edit_nws"] = W.data, nws
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_plans_follow_the_variable_and_table_edits(tmp_path, oracle_lib):
+    """Plans are cached per (variable, method) but the flags on a device belong to the grid: u, v, u, w, v in turn --
+    three different Neumann planes -- and then an in-place edit of v's flag row must each give that variable's matrix
+    (round-2 advisor finding: the third call ran with v's flags).  With the oracle as compute this pins the plumbing
+    (gather_neumann re-derived per call, buffers switched); tests/test_gpu_sharded.py repeats it on the real device state."""
+    world = 2
+    mp.spawn(_worker_alternate, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mesh = _make_mesh("twovars")
+    o = oracle_lib.OracleInterpolator("port", threads=1)
+    o.load_mesh(mesh)
+    ref = {v: o.interpolate(v, "gls") for v in ("u", "v", "w")}
+    assert not np.array_equal(ref["u"][1], ref["w"][1]) and not ref["v"][1].any()
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        for i, var in enumerate(("u", "v", "u", "w", "v")):
+            np.testing.assert_array_equal(z[f"{i}_data"], ref[var][0].data)
+            np.testing.assert_array_equal(z[f"{i}_nws"], ref[var][1])
+    row = o.variable_to_index["points"]
+    o.points_data[row["neumann_flag_v"]][:] = o.points_data[row["neumann_flag_w"]]
+    W, nws = o.interpolate("v", "gls")
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        np.testing.assert_array_equal(z["edit_data"], W.data)
+        np.testing.assert_array_equal(z["edit_nws"], nws)
 
 
 def test_extract_submesh_invariants():
