@@ -6,16 +6,23 @@
 
 A "step" is one pass of the hot path over the rank's shard: the GLS weight kernel over every node
 (inputs resident in HBM, output written in CSR position on the device) and, for N > 1, the one
-all-gather over RCCL that reassembles the (count, column, value) triplets on every rank.
+all-gather over RCCL that reassembles the (count, column, value) triplets on every rank.  For N > 1 the line
+also decomposes itself: `compute_only_Mnodes_s` (the kernels with no exchange), `exchange_ms` (the all-gather of one
+step's values timed alone) and `apply_Mnodes_s` -- the sharded W . u (each rank applies its own row block, one
+all-gather of 8 B per node), which is what the reference's callers do with the matrix.
 
 Workload (BASELINE.json: "GLS, 10M-cell hex mesh"): 216^3 = 10,077,696 hexahedra per GPU,
 nodes jittered U(-0.15h, 0.15h), K = the ALH tensor at the centroids, all-Dirichlet boundary flags.
-With N GPUs the box grows to 216 x 216 x 216 N cells (weak scaling): rank r owns a contiguous block of
-node planes, replicates one cell layer on each interior side, and no rank ever holds the whole mesh.
+With N GPUs the box grows to 216 x 216 x 216 N cells (weak scaling; at N = 8 the same 80.6 M cells as SURVEY's
+432^3 in a different aspect): rank r owns a contiguous block of node planes, replicates one cell layer on each interior
+side, and no rank ever holds the whole mesh.  `--edge-global G` instead fixes the WHOLE mesh at G^3 cells and splits its
+node planes over the ranks (strong scaling; BASELINE config [4] as SURVEY wrote it: --gpus 8 --edge-global 432).
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
-  roofline      of the dominant kernel, duration measured with HIP events on the launch stream.  GLS: bound "fp64"
-                (executed flops / time against the FP64 vector peak) with the HBM figure -- algorithmic bytes of
+  roofline      of the dominant kernel, duration measured with HIP events on the launch stream.  GLS: bound "fp64":
+                `achieved` = ALGORITHMIC flops of the multifrontal formulation (tools/count_algorithmic_flops.py:
+                15 869 per cube node) x the nodes the kernel processes / time against the FP64 vector peak; the flops the
+                kernel EXECUTES (ISA count) ride beside it as `executed_*`, the HBM figure -- algorithmic bytes of
                 SURVEY 8d / time against 8 TB/s -- as `hbm` / `hbm_frac`; IDW, LS: bound "hbm".  `traffic` from
                 profiles/traffic.json when a PMC run of exactly these kernel sources has been recorded, else null
   cpu_baseline  our C restatement of the reference's method kernel (kind "port"; the reference itself never
@@ -43,6 +50,22 @@ REF_FLOPS_PER_NODE_HEX = 74.8e3   # dgels 44 x 25 x 8 per interior he
 # FP64 operations the multifrontal kernel EXECUTES per interior hexahedron node (fma = 2, mul / add = 1, the 4 lanes
 # of a node summed), counted on the kernel's ISA by tools/count_fp64.py (profiles/r02/hex8mf_isa_mix.txt)
 EXEC_FLOPS_PER_NODE_HEX = 20.5e3
+# ALGORITHMIC FP64 flops per node of the multifrontal formulation -- useful arithmetic only, no role masks, no redundant
+# panel work (tools/count_algorithmic_flops.py, profiles/r03/algorithmic_flops.txt) -- by node kind: (fronts, dense cells)
+ALG_FLOPS = {"cube": 15869.0, "kuhn": 250357.0, "wedge": 40075.0}
+REF_FLOPS = {"cube": 74783.0, "kuhn": 1944671.0, "wedge": 247727.0}   # dense dgels on the same nodes
+
+
+def gls_flops_of_plan(plan_counts, mx_elems):
+    """Algorithmic flops one GLS launch performs on the nodes whose kind is known from the launch plan: the cube-node
+    kernel's nodes, the multifrontal kernel's Kuhn (12 + 12) nodes and its small instantiation's nodes (wedge 6 + 6 on a
+    wedge mesh, cube 4 + 4 when the cube-node kernel is off).  General-kind and block-kernel nodes (interfaces, apexes,
+    Neumann boundary nodes: 6 % of BASELINE config [3]'s computed nodes) are NOT priced -- returned as `unpriced`."""
+    small = "wedge" if mx_elems >= 12 else "cube"
+    alg = plan_counts["hex8"] * ALG_FLOPS["cube"] + plan_counts["mfw_large"] * ALG_FLOPS["kuhn"] + plan_counts["mfw_small"] * ALG_FLOPS[small]
+    ref = plan_counts["hex8"] * REF_FLOPS["cube"] + plan_counts["mfw_large"] * REF_FLOPS["kuhn"] + plan_counts["mfw_small"] * REF_FLOPS[small]
+    unpriced = sum(v for k, v in plan_counts.items() if k not in ("hex8", "mfw_large", "mfw_small"))
+    return alg, ref, unpriced
 
 
 def kernel_source_hash():
@@ -114,6 +137,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--method", default="gls", choices=["gls", "idw", "ls"])
     ap.add_argument("--edge", dest="n", type=int, default=216, help="cells per edge per GPU (216^3 = 10,077,696)")
+    ap.add_argument("--edge-global", type=int, default=0,
+                    help="strong scaling: the WHOLE mesh is G^3 cells, its node planes split over the ranks (e.g. 432 with --gpus 8)")
     ap.add_argument("--jitter", type=float, default=0.15)
     ap.add_argument("--cpu-sample", type=int, default=128, help="edge of the CPU-baseline sample mesh (0 = skip)")
     ap.add_argument("--grid-build", default="host", choices=["host", "device"],
@@ -155,12 +180,14 @@ def main():
     from ninpol_amd import mesh as M
     from ninpol_amd.partition import ShardedInterpolator, node_block
 
-    n = args.n
-    nz_global = n * world
+    strong = args.edge_global > 0
+    n = args.edge_global if strong else args.n
+    nz_global = n if strong else n * world
+    zlen = 1.0 if strong else float(world)
     plane_lo, plane_hi = node_block(nz_global + 1, rank, world)
     t0 = time.time()
     mesh, node_off, cell_off, own_lo, own_hi = M.hex_slab(n, n, nz_global, plane_lo, plane_hi,
-                                                          lengths=(1.0, 1.0, float(world)), jitter=args.jitter, seed=0)
+                                                          lengths=(1.0, 1.0, zlen), jitter=args.jitter, seed=0)
     M.attach_fields(mesh, "u", perm="ALH")
     t_gen = time.time() - t0
     t0 = time.time()
@@ -197,6 +224,7 @@ def main():
         plan = I.device_plan("u", args.method)
     t_push = time.time() - t0
     P_loc, n_owned = g.n_points, own_hi - own_lo
+    gls_counts = g.gls_plan() if args.method == "gls" else None
 
     stream = torch.cuda.current_stream()
     if world == 1:
@@ -246,10 +274,50 @@ def main():
     else:
         total_nodes = n_owned
 
+    def timed_leg(body, finish):
+        """K calls of body(i) + finish(), bracketed like the main loop; max over ranks, in ms per call."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            body(i)
+        finish()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt[0])
+        return dt / max(args.steps, 1) * 1e3
+
+    decomposition = {}
+    if world > 1:
+        # (1) the kernels alone, no exchange; (2) one step's exchange alone (its buffers hold the last step's values);
+        # (3) the sharded apply: W_block . u on the device + the all-gather of node values (ShardedPlan.apply_step)
+        decomposition["compute_only_ms"] = timed_leg(lambda i: splan.step(exchange=False), lambda: None)
+        decomposition["exchange_ms"] = timed_leg(lambda i: (splan.drain(i % 2), splan.exchange(i % 2)), splan.drain_all)
+        u_loc = torch.from_numpy(np.ascontiguousarray(
+            np.asarray(I.cells_data[I.variable_to_index["cells"]["u"]])[:g.n_elems].reshape(1, -1))).to(dev)
+        splan.apply_step(u_loc)
+        splan.drain_all()
+        decomposition["apply_ms"] = timed_leg(lambda i: splan.apply_step(u_loc), splan.drain_all)
+    else:
+        u_loc = torch.from_numpy(np.ascontiguousarray(
+            np.asarray(I.cells_data[I.variable_to_index["cells"]["u"]])[:g.n_elems].reshape(1, -1))).to(dev)
+        node_vals = torch.empty((1, P_loc), dtype=torch.float64, device=dev)
+        plan.launch_apply(u_loc.data_ptr(), 1, node_vals.data_ptr(), nws.data_ptr(), stream.cuda_stream)
+        decomposition["apply_ms"] = timed_leg(
+            lambda i: plan.launch_apply(u_loc.data_ptr(), 1, node_vals.data_ptr(), nws.data_ptr(), stream.cuda_stream), lambda: None)
+        del node_vals
+
     check = None
     if args.check and world > 1 and rank == 0:
         # reassemble what the all-gather delivered and compare with the whole mesh computed on this GPU
-        whole = M.hex_mesh(n, n, nz_global, lengths=(1.0, 1.0, float(world)), jitter=args.jitter, seed=0)
+        whole = M.hex_mesh(n, n, nz_global, lengths=(1.0, 1.0, zlen), jitter=args.jitter, seed=0)
         M.attach_fields(whole, "u", perm="ALH")
         Iw = ninpol_amd.Interpolator(device=local_rank)
         Iw.load_mesh(mesh_obj=whole)
@@ -283,9 +351,15 @@ def main():
         if args.method == "gls":
             # GLS is FP64-ALU-bound, not HBM-bound (SURVEY finding 2): the roofline of record is the FP64 vector peak,
             # priced on the flops the kernel EXECUTES; the HBM fraction (BASELINE's metric) rides beside it
-            ex = EXEC_FLOPS_PER_NODE_HEX * P_loc / (kern_ms * 1e-3) / 1e12
-            roof = {"bound": "fp64", "achieved": round(ex, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ex / FP64_PEAK_TFLOPS, 4), "executed_flops_per_node": EXEC_FLOPS_PER_NODE_HEX,
+            # the flops are priced on the nodes the kernel PROCESSES (Dirichlet boundary nodes are skipped: 2.7 % at 216^3)
+            n_cube = gls_counts["hex8"]
+            alg = ALG_FLOPS["cube"] * n_cube / (kern_ms * 1e-3) / 1e12
+            ex = EXEC_FLOPS_PER_NODE_HEX * n_cube / (kern_ms * 1e-3) / 1e12
+            roof = {"bound": "fp64", "achieved": round(alg, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(alg / FP64_PEAK_TFLOPS, 4), "algorithmic_flops_per_node": ALG_FLOPS["cube"],
+                    "nodes_processed": n_cube,
+                    "executed_flops_per_node": EXEC_FLOPS_PER_NODE_HEX, "executed_tflops": round(ex, 3),
+                    "executed_frac": round(ex / FP64_PEAK_TFLOPS, 4),
                     "hbm": hbm, "hbm_frac": hbm["frac"]}
         else:
             roof = dict(hbm, bound="hbm")
@@ -295,20 +369,32 @@ def main():
             "metric": "Mnodes/s interpolated (GLS, 10M-cell hex mesh) + achieved HBM GB/s vs peak"
                       if args.method == "gls" and n == 216 else f"Mnodes/s interpolated ({args.method.upper()}, {n}^3-cell hex mesh per GPU)",
             "value": round(value, 3), "unit": "Mnodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.method.upper()} interpolate() weights, {n}x{n}x{n * world} hexahedra "
-                                   f"({n ** 3 * world} cells, {total_nodes} nodes), jitter {args.jitter}, ALH permeability, "
+            "config": {"workload": f"{args.method.upper()} interpolate() weights, {n}x{n}x{nz_global} hexahedra "
+                                   f"({n * n * nz_global} cells, {total_nodes} nodes), jitter {args.jitter}, ALH permeability, "
                                    "all-Dirichlet boundary; inputs resident in HBM, output CSR values on device"
                                    + ("; + RCCL all-gather of the (count, column, value) triplets and the Neumann array: columns "
                                       "and counts once per mesh, values per step, overlapped with the next step's kernel "
                                       "(ShardedPlan, two buffer sets)" if world > 1 else ""),
-                       "cells_per_gpu": n ** 3, "nodes_total": total_nodes, "nnz_esup_rank0": plan.nnz,
+                       "cells_per_gpu": n * n * nz_global // world, "nodes_total": total_nodes, "nnz_esup_rank0": plan.nnz,
                        "parallelism": f"node-block shards x{world}, neighbour cells replicated" if world > 1 else "single GPU"},
             "roofline": roof,
             "setup_s": {"mesh_gen": round(t_gen, 2), "load_mesh": round(t_load, 2), "push_to_hbm": round(t_push, 2),
                         "grid_build": args.grid_build},
         }
+        if "compute_only_ms" in decomposition:
+            line["compute_only_Mnodes_s"] = round(total_nodes / decomposition["compute_only_ms"] / 1e3, 3)
+            line["exchange_ms"] = round(decomposition["exchange_ms"], 4)
+            line["exchange_note"] = ("all-gather of one step's CSR values (8 B per entry" +
+                                     (" + 8 B per row of neumann_ws" if splan.gather_neumann else "") +
+                                     f"), timed alone: {splan.mx_nnz * 8 * (world - 1) / 1e9:.3f} GB received per GPU")
+        line["apply_Mnodes_s"] = round(total_nodes / decomposition["apply_ms"] / 1e3, 3)
+        line["apply_ms_per_step"] = round(decomposition["apply_ms"], 4)
+        line["apply_note"] = ("W . u for one cell field: weights + row-block apply on the device" +
+                              (f" + ONE all-gather of node values ({splan.mx_rows * 8 * (world - 1) / 1e6:.1f} MB received per GPU)"
+                               if world > 1 else "") + "; what the reference's callers do with the matrix (analytical.py:236)")
         if t_load_dev is not None:
             line["setup_s"]["load_mesh_with_device_grid_build"] = round(t_load_dev, 2)
         if check is not None:
@@ -316,12 +402,14 @@ def main():
         if rehearsal:
             line["data"] = "synthetic (REHEARSAL: all ranks on one GPU, gloo through host copies -- not a measurement)"
         if args.method == "gls":
-            flops = REF_FLOPS_PER_NODE_HEX * P_loc / (kern_ms * 1e-3) / 1e12
+            flops = REF_FLOPS_PER_NODE_HEX * gls_counts["hex8"] / (kern_ms * 1e-3) / 1e12
             line["fp64"] = {"ref_equiv_tflops": round(flops, 3), "peak_tflops": FP64_PEAK_TFLOPS,
                             "ref_equiv_frac": round(flops / FP64_PEAK_TFLOPS, 4),
-                            "executed_tflops": roof["achieved"], "executed_frac": roof["frac"],
+                            "algorithmic_tflops": roof["achieved"], "algorithmic_frac": roof["frac"],
+                            "executed_tflops": roof["executed_tflops"], "executed_frac": roof["executed_frac"],
                             "note": "ref_equiv prices the node rate at the reference's dense dgels 44x25x8 = 74.8 kflop/node "
-                                    "(SURVEY 8d); the multifrontal kernel executes ~20.5 kflop/node, so ref_equiv may pass 1"}
+                                    "(SURVEY 8d); the multifrontal formulation needs 15.9 kflop/node (algorithmic) and the kernel "
+                                    "executes 20.5 (role masks, redundant panel work), so ref_equiv may pass 1"}
         if world == 1 and not args.no_extras:
             # context: the two HBM-bound methods on the same grid, and end-to-end interpolate()
             for meth in ("idw", "ls"):
@@ -369,8 +457,15 @@ def main():
                     torch.cuda.synchronize()
                     ms = a.elapsed_time(b) / reps
                     gb = po.algorithmic_bytes / (ms * 1e-3) / 1e9
-                    return {"kernel_ms": round(ms, 3), "Mnodes_per_s": round(Io.grid.n_points / ms / 1e3, 2),
-                            "achieved_GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBS, 4)}
+                    row = {"kernel_ms": round(ms, 3), "Mnodes_per_s": round(Io.grid.n_points / ms / 1e3, 2),
+                           "achieved_GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBS, 4)}
+                    if meth == "gls":   # the roof that binds GLS: FP64 vector, algorithmic flops of the multifrontal formulation
+                        alg, ref, unpriced = gls_flops_of_plan(Io.grid.gls_plan(), Io.grid.MX_ELEMENTS_PER_POINT)
+                        row.update({"fp64_algorithmic_tflops": round(alg / (ms * 1e-3) / 1e12, 3),
+                                    "fp64_frac": round(alg / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                                    "fp64_ref_equiv_frac": round(ref / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                                    "nodes_not_priced": int(unpriced)})
+                    return row
                 rows = {}
                 for name, make, meths in (
                         ("[1],[2] hex 100^3", lambda: M.hex_mesh(100, jitter=args.jitter), ("idw", "gls")),

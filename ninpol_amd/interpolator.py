@@ -356,8 +356,7 @@ class Interpolator:
             raise ValueError(f"Method '{method}' not supported. Supported methods are: "
                              f"{list(self.supported_methods.keys())}")
         target_points = np.asarray(target_points, dtype=DTYPE_I)
-        if len(target_points) == 0:
-            target_points = np.arange(self.grid.n_points, dtype=DTYPE_I)
+        every_node = len(target_points) == 0    # interpolator.pyx:557-558: an empty list means all nodes
         if variable not in self.variable_to_index["cells"]:
             raise ValueError(f"Variable '{variable}' not found in cells data. "
                              "Point -> Cell interpolation not supported yet.")
@@ -375,7 +374,8 @@ class Interpolator:
         if g.device < 0:
             g.to_device(self.device)
         t0 = time.time()
-        full = len(target_points) == P and np.array_equal(target_points, np.arange(P))
+        # (the identity list is only materialised when somebody asks for it: arange + compare cost 20 ms at 10 M nodes)
+        full = every_node or (len(target_points) == P and np.array_equal(target_points, np.arange(P)))
         idx_t = np.int32 if max(g.nnz_esup, E, P) < np.iinfo(np.int32).max else np.int64
         if full and idx_t is np.int32:
             # one native call: kernel with `data[j] = weights + neumann_ws[row]` (interpolator.pyx:618) fused, then the
