@@ -128,3 +128,65 @@ def test_10m_mixed_gls_at_size(oracle_lib):
         worst = max(worst, util.csr_rowscaled_err(Wg, Wg.indptr, Wg.indices, Wo.data))
         n_checked += 512
     assert n_checked == 4096 and worst <= util.WEIGHT_RTOL, worst
+
+
+def test_80m_hex_gls_single_gpu_properties(oracle_lib):
+    """BASELINE config [4]'s mesh -- 432^3 = 80,621,568 hexahedra, 81,182,737 nodes -- whole on ONE MI355X
+    (36 GB of its 288 GB): device grid build, GLS, and the size-independent properties WITHOUT bringing 640 M entries to
+    the host: row sums through the device-side apply on a constant field (1 on every computed row, exactly 0 on the
+    empty Dirichlet rows), nnz and the row pattern through the device-side count / scan alone
+    (nin_csr_compact_host with no entry buffers): nnz == 8 . 431^3, 8 entries on every interior node, none on the
+    boundary; plus the oracle itself on two runs of 256 consecutive nodes cut out of the big mesh."""
+    import ctypes
+    import torch
+    import ninpol_amd
+    from ninpol_amd import _lib
+    from ninpol_amd.partition import extract_submesh
+    n = 432
+    mesh = M.hex_mesh(n, jitter=0.15, seed=0)
+    M.attach_fields(mesh, "u", perm="ALH")
+    I = ninpol_amd.Interpolator(grid_build="device")
+    I.load_mesh(mesh_obj=mesh)
+    P, E = I.grid.n_points, I.grid.n_elems
+    assert E == 80_621_568 and P == 81_182_737 and I.grid.n_faces == 3 * n * n * (n + 1)
+    plan_counts = None
+    # -- row sums: W . 1 on the device
+    ones = np.ones(E)
+    sums, nws = I.apply("u", "gls", values=ones)
+    plan_counts = I.grid.gls_plan()
+    assert plan_counts["hex8"] == (n - 1) ** 3, plan_counts          # every interior node is a cube node
+    k = np.arange(P)
+    i, j, l = k % (n + 1), (k // (n + 1)) % (n + 1), k // ((n + 1) * (n + 1))
+    interior = (i > 0) & (i < n) & (j > 0) & (j < n) & (l > 0) & (l < n)
+    del i, j, l, k
+    assert np.all(sums[~interior] == 0.0) and not nws.any()
+    assert np.abs(sums[interior] - 1.0).max() <= 1e-10
+    del sums, ones
+    # -- the pattern, counted on the device: weights into a device buffer, count + scan, only indptr comes back
+    dp = I.device_plan("u", "gls")
+    out = torch.empty(dp.nnz, dtype=torch.float64, device="cuda")
+    dn = torch.empty(P, dtype=torch.float64, device="cuda")
+    dp.launch(out.data_ptr(), dn.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    indptr = np.empty(P + 1, dtype=np.int32)
+    nnz = ctypes.c_int64(0)
+    _lib.check(_lib.load().nin_csr_compact_host(I.grid._h, ctypes.c_void_p(out.data_ptr()), indptr.ctypes.data_as(ctypes.c_void_p),
+                                                None, None, ctypes.byref(nnz), None))
+    assert nnz.value == 8 * (n - 1) ** 3 == 640_503_928
+    cnt = np.diff(indptr)
+    assert np.all(cnt[interior] == 8) and not cnt[~interior].any()
+    # -- the oracle on two runs of nodes cut out of the big mesh (rows of the whole mesh, see test_10m_mixed_gls_at_size)
+    esup_ptr = np.asarray(I.grid.esup_ptr)
+    for lo in (40_000_000, 81_000_000):
+        sub, pid, cid, owned = extract_submesh(mesh, lo, lo + 256)
+        o = oracle_lib.OracleInterpolator("port", threads=8)
+        o.load_mesh(sub)
+        wo, _ = o.prepare("gls", "u")
+        b, e = int(esup_ptr[lo]), int(esup_ptr[lo + 256])
+        got = out[b:e].cpu().numpy()
+        ref = np.concatenate([wo[p, :esup_ptr[lo + q + 1] - esup_ptr[lo + q]] for q, p in enumerate(owned)])
+        rows = np.repeat(np.arange(256), np.diff(esup_ptr[lo:lo + 257]))
+        scale = np.zeros(256)
+        np.maximum.at(scale, rows, np.abs(ref))
+        scale[scale == 0] = 1.0
+        assert (np.abs(got - ref) / scale[rows]).max() <= util.WEIGHT_RTOL
