@@ -20,7 +20,6 @@
 #include <omp.h>
 
 #include <algorithm>
-#include <parallel/algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -33,6 +32,28 @@
 namespace nin {
 
 namespace {
+
+// Sort by the library's own team: chunks sorted in parallel, then merged pairwise.  (libstdc++'s parallel-mode sort was
+// used here in round 2; its multiway_mergesort.h lets every thread of the team store the team size into one shared
+// variable without synchronisation -- a data race by the letter, reported by ThreadSanitizer -- and sizes its team from the
+// process-wide OpenMP default.)
+template <class T>
+void team_sort(std::vector<T> &v) {
+    const int nt = host_team();
+    const size_t n = v.size();
+    if (nt <= 1 || n < ((size_t)1 << 16)) { std::sort(v.begin(), v.end()); return; }
+    const int chunks = nt;
+    std::vector<size_t> cut((size_t)chunks + 1);
+    for (int c = 0; c <= chunks; ++c) cut[(size_t)c] = n * (size_t)c / (size_t)chunks;
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+    for (int c = 0; c < chunks; ++c) std::sort(v.begin() + (ptrdiff_t)cut[c], v.begin() + (ptrdiff_t)cut[c + 1]);
+    for (int w = 1; w < chunks; w *= 2) {
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int c = 0; c < chunks - w; c += 2 * w)
+            std::inplace_merge(v.begin() + (ptrdiff_t)cut[c], v.begin() + (ptrdiff_t)cut[c + w],
+                               v.begin() + (ptrdiff_t)cut[std::min(c + 2 * w, chunks)]);
+    }
+}
 
 inline bool elem_has_point(const int32_t *el, int n, int32_t p) {
     for (int i = 0; i < n; ++i)
@@ -462,13 +483,13 @@ void HostGrid::build_inedel() {
             kv[(size_t)(start[i] + j)] = ((uint64_t)key << 32) | (uint64_t)(start[i] + j);
         }
     }
-    __gnu_parallel::sort(kv.begin(), kv.end(), std::less<uint64_t>(), __gnu_parallel::default_parallel_tag((unsigned)host_team()));
+    team_sort(kv);
     std::vector<uint64_t> firsts;          // position of the first sight of every key, then sorted ascending
     firsts.reserve((size_t)N / 3 + 16);
     for (int64_t q = 0; q < N; ++q)
         if (q == 0 || (kv[q] >> 32) != (kv[q - 1] >> 32)) firsts.push_back(kv[q] & 0xffffffffu);
     std::vector<uint64_t> by_pos(firsts);
-    __gnu_parallel::sort(by_pos.begin(), by_pos.end(), std::less<uint64_t>(), __gnu_parallel::default_parallel_tag((unsigned)host_team()));
+    team_sort(by_pos);
     n_edges = (int64_t)by_pos.size();
     // element / local edge of a walk position (binary search over the per-element starts)
     auto locate = [&](int64_t pos, int64_t *e, int *j) {
