@@ -231,10 +231,187 @@ __device__ __forceinline__ void rows_block(double (&a)[NC], double (&b)[NC], dou
     }
 }
 
-template <int FM, int DM, bool ROWS_IN_LANES, bool GENERAL>
+// ---- the dense problem in STRIPS: the matrix unit does the cross-lane sums ------------------------------------------------
+// v_mfma_f64_4x4x4_4b (tools/micro_mfma64.hip: 16 cycles, 512 flops -- the FP64 matrix peak of an MI355X equals its vector
+// peak, so nothing is gained in arithmetic; what is gained is that the instruction SUMS ACROSS LANES): with a register read
+// as a 4 x 16 strip S[k][c], k = lane >> 4, c = lane & 15 = 4 quad + j, it computes, quad by quad,
+//         D_quad = (S1_quad)^T  S2_quad + C_quad          (4 x 4 blocks; D, S2, C in the same strip layout)
+// i.e. a contraction over the strip's row index.  The dense (7 F + D) x (3 D + 1) problem is held as 16-row x 4-column tiles,
+// one per register: lane (i = lane >> 4, quad, j = lane & 3) of tile [q][cb] = row 16 q + 4 quad + i, column 4 cb + j.  A panel of
+// four reflectors (compact WY: H_0 .. H_3 = I - V T V^T, tools/proto_mfw.py dense_blocked) then needs, per trailing column
+// block: W = V^T C (one instruction per row tile, the four quads' partial sums joined by two DPP adds), W' = T^T W (one
+// instruction), C -= V W' (one per row tile) -- against one 64-lane reduction and two v_readlane per COLUMN AND REFLECTOR in the
+// row-lane form.  Only the panel itself (4 columns) is factored by the vector unit, one reduction per step for all its columns.
+// After a panel the column blocks move down by one register, so one body serves every panel.
+__device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+// sum over the four quads of a 16-lane row, in every quad
+__device__ __forceinline__ double sum_quads(double v) {
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    return v;
+}
+// sum over the four 16-lane rows, in every row
+__device__ __forceinline__ double sum_rows(double v) {
+    double x = v, y = v;
+    swap16(x, y);
+    v = x + y;
+    x = v; y = v;
+    swap32(x, y);
+    return x + y;
+}
+template <int K>
+__device__ __forceinline__ double quad_pick(double v) { return dpp_mov<K * 0x55>(v); }   // quad_perm [K,K,K,K]
+
+// two sums over the four 16-lane rows at once: a and b each summed over the rows, in every row (8 instructions, not 12)
+__device__ __forceinline__ void sum_rows2(double &a, double &b) {
+    swap16(a, b);             // a = [a0 b0 a2 b2], b = [a1 b1 a3 b3]
+    double s = a + b;         //     [a01 b01 a23 b23]
+    double x = s, y = s;
+    swap32(x, y);             // x = [a01 b01 a01 b01], y = [a23 b23 a23 b23]
+    s = x + y;                //     [A B A B]
+    a = s; b = s;
+    swap16(a, b);             // a = [A A A A], b = [B B B B]
+}
+
+// One panel step K on the panel's tiles P[q], q >= Q0 (column block 0): pivot row rp = 4 p + K = (tile Q0, quad bp, i = K).
+// Tiles above Q0 hold rows below every pivot of this panel: no masks there.  vp[K], gk[K]: the reflector's pivot entry and scalar.
+template <int NQ, int Q0, int K>
+__device__ __forceinline__ void strip_panel_step(double (&P)[NQ], double (&vp)[4], double (&gk)[4], int bp, int si, int sb, int sj) {
+    const bool in_piv_quad = sb == bp;
+    const bool is_piv = in_piv_quad && si == K;                  // this lane's row of tile Q0 is the pivot row
+    const bool below0 = sb > bp || (in_piv_quad && si > K);      // ... lies below it
+    double xm[NQ], acc = 0.0;
+#pragma unroll
+    for (int q = Q0; q < NQ; ++q) {
+        const double xk = quad_pick<K>(P[q]);
+        xm[q] = (q == Q0 && !below0) ? 0.0 : xk;                 // the reflector's entries below the pivot
+        acc = fma(xm[q], P[q], acc);                             // lane (.., j): sum over its rows of a[r][K] a[r][j]
+    }
+    double d = sum_quads(acc), ap = sum_quads(is_piv ? P[Q0] : 0.0);   // (the pivot row's entry of column j, from its quad)
+    sum_rows2(d, ap);
+    const House h = house_unguarded(quad_pick<K>(ap), quad_pick<K>(d));
+    const double w = sj > K ? -(h.g * fma(h.vp, ap, d)) : 0.0;   // w_j = -g (v . a_j), the panel's later columns only
+    gk[K] = h.g;
+    vp[K] = h.vp;
+#pragma unroll
+    for (int q = Q0; q < NQ; ++q) {
+        double x = fma(w, q == Q0 && is_piv ? h.vp : xm[q], P[q]);
+        if (q == Q0) x = (is_piv && sj == K) ? h.beta : x;       // R(rp, rp)
+        P[q] = x;
+    }
+}
+
+// Panel p (tiles Q0 .. NQ - 1; NT trailing column blocks at most): factor it, apply it, store its rows of R.
+template <int NQ, int NCB, int Q0, int NT>
+__device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc, int si, int sb, int sj, double eye, double *Rm, int RP) {
+    const int bp = p & 3, steps = nc - 4 * p < 4 ? nc - 4 * p : 4;
+    double V[NQ], gk[4] = {0.0, 0.0, 0.0, 0.0}, vp[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+        double P[NQ];
+#pragma unroll
+        for (int q = Q0; q < NQ; ++q) P[q] = C[q][0];
+        strip_panel_step<NQ, Q0, 0>(P, vp, gk, bp, si, sb, sj);
+        if (steps > 1) strip_panel_step<NQ, Q0, 1>(P, vp, gk, bp, si, sb, sj);
+        if (steps > 2) strip_panel_step<NQ, Q0, 2>(P, vp, gk, bp, si, sb, sj);
+        if (steps > 3) strip_panel_step<NQ, Q0, 3>(P, vp, gk, bp, si, sb, sj);
+#pragma unroll
+        for (int q = Q0; q < NQ; ++q) { C[q][0] = P[q]; V[q] = P[q]; }
+        // V: below the pivots the panel's columns ARE the reflectors; in the pivot quad the diagonal takes v's pivot entries,
+        // everything above it (R) and every row above the quad (earlier panels' rows of R) is zero; no reflector, no column
+        const double vdiag = sj == 0 ? vp[0] : sj == 1 ? vp[1] : sj == 2 ? vp[2] : vp[3];
+        double v0 = V[Q0];
+        v0 = (sb == bp && si == sj) ? vdiag : v0;
+        v0 = (sb < bp || (sb == bp && si < sj)) ? 0.0 : v0;
+        V[Q0] = v0;
+        if (steps < 4) {
+#pragma unroll
+            for (int q = Q0; q < NQ; ++q) V[q] = sj < steps ? V[q] : 0.0;
+        }
+    }
+    if (NT > 0) {
+        // T: T[k][k] = g_k, T[0:k, k] = -g_k T[0:k, 0:k] (V^T v_k); G = V^T V by the matrix unit
+        double G = 0.0;
+#pragma unroll
+        for (int q = Q0; q < NQ; ++q) G = mfma4(V[q], V[q], G);
+        G = sum_quads(G);                                        // lane (i, ., j): G[i][j]
+        const double G01 = rl64(G, 1), G02 = rl64(G, 2), G03 = rl64(G, 3), G12 = rl64(G, 18), G13 = rl64(G, 19), G23 = rl64(G, 35);
+        const double T00 = gk[0], T11 = gk[1], T22 = gk[2], T33 = gk[3];
+        const double T01 = -T11 * (T00 * G01);
+        const double T02 = -T22 * fma(T01, G12, T00 * G02), T12 = -T22 * (T11 * G12);
+        const double T03 = -T33 * fma(T02, G23, fma(T01, G13, T00 * G03)), T13 = -T33 * fma(T12, G23, T11 * G13), T23 = -T33 * (T22 * G23);
+        // the strip T[k][i] at lane (k = si, ., i = sj); zero below the diagonal
+        double Ts = 0.0;
+        Ts = si == 0 ? (sj == 0 ? T00 : sj == 1 ? T01 : sj == 2 ? T02 : T03) : Ts;
+        Ts = si == 1 ? (sj == 1 ? T11 : sj == 2 ? T12 : sj == 3 ? T13 : 0.0) : Ts;
+        Ts = si == 2 ? (sj == 2 ? T22 : sj == 3 ? T23 : 0.0) : Ts;
+        Ts = si == 3 ? (sj == 3 ? T33 : 0.0) : Ts;
+        // W[cb] = V^T C[.][cb]: NT independent accumulation chains (blocks past the live ones hold zeros: harmless)
+        double W[NT + 1];
+#pragma unroll
+        for (int cb = 1; cb <= NT; ++cb) W[cb] = 0.0;
+#pragma unroll
+        for (int q = Q0; q < NQ; ++q) {
+#pragma unroll
+            for (int cb = 1; cb <= NT; ++cb) W[cb] = mfma4(V[q], C[q][cb], W[cb]);
+        }
+#pragma unroll
+        for (int cb = 1; cb <= NT; ++cb) W[cb] = sum_quads(W[cb]);
+#pragma unroll
+        for (int cb = 1; cb <= NT; ++cb) W[cb] = -mfma4(Ts, W[cb], 0.0);       // -(T^T W), the same in every quad
+        // C -= V W': the A operand is V^T per quad (one instruction with the identity transposes a tile)
+#pragma unroll
+        for (int q = Q0; q < NQ; ++q) {
+            const double VT = mfma4(V[q], eye, 0.0);
+#pragma unroll
+            for (int cb = 1; cb <= NT; ++cb) C[q][cb] = mfma4(VT, W[cb], C[q][cb]);
+        }
+    }
+    // rows 4 p .. 4 p + steps - 1 of R are final: tile Q0, quad bp
+#pragma unroll
+    for (int cb = 0; cb <= NT; ++cb) {
+        const int col = 4 * (p + cb) + sj;
+        if (sb == bp && si < steps && col <= nc && (cb > 0 || sj >= si)) Rm[(4 * p + si) * RP + col] = C[Q0][cb];
+    }
+    if (steps == 4) {                                            // the next panel (or c) moves into block 0
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int cb = 0; cb < NT; ++cb) C[q][cb] = C[q][cb + 1];
+            C[q][NT] = 0.0;
+        }
+    }
+}
+
+// The whole dense factorisation.  On entry C[q][cb] = the tiles (c at column nc); on exit R's rows 0 .. nc - 1 (columns up to
+// nc = Q^T c) are in LDS at Rm[row * RP + col] and the return value is r . r = |(Q^T c)(nc:)|^2.  Panels 4 Q0 .. 4 Q0 + 3 pivot in
+// tile Q0; they have at most NCB - 1 - 4 Q0 trailing blocks (the first of them; the later ones sweep a few zero blocks too).
+template <int NQ, int NCB>
+__device__ __forceinline__ double strip_factor(double (&C)[NQ][NCB], int nc, int lane, double *Rm, int RP) {
+    const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3, rowbase = 4 * sb + si;
+    const double eye = si == sj ? 1.0 : 0.0;                     // the 4 x 4 identity in every quad
+    const int n_panels = (nc + 3) >> 2;
+    static_assert(NQ >= 3 && NCB <= 12, "three generations of panels");
+    for (int p = 0; p < (n_panels < 4 ? n_panels : 4); ++p) strip_panel<NQ, NCB, 0, NCB - 1>(C, p, nc, si, sb, sj, eye, Rm, RP);
+    if constexpr (NCB > 5) {
+        for (int p = 4; p < (n_panels < 8 ? n_panels : 8); ++p) strip_panel<NQ, NCB, 1, NCB - 5>(C, p, nc, si, sb, sj, eye, Rm, RP);
+    }
+    if constexpr (NCB > 9) {
+        for (int p = 8; p < n_panels; ++p) strip_panel<NQ, NCB, 2, NCB - 9>(C, p, nc, si, sb, sj, eye, Rm, RP);
+    }
+    // c sits in block 0, column nc & 3; r . r over the rows that never were pivot rows
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double x = (16 * q + rowbase >= nc && sj == (nc & 3)) ? C[q][0] : 0.0;
+        t = fma(x, x, t);
+    }
+    return wave_allsum(t);
+}
+
+template <int FM, int DM, bool ROWS_IN_LANES, bool GENERAL, bool STRIPS = false>
 // (3 wavefronts per SIMD pay for the small instantiation -- wedge60 2.95 -> 2.72 ms, 160 B of spills; the large one spills
 //  inside its steps at 168 registers: 1.80 -> 2.32 ms)
-__global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
+__global__ __launch_bounds__(256, (FM <= kMfwSmallFronts && !STRIPS ? 3 : 2)) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                               const uint32_t *__restrict__ desc, int32_t count,
                                                               int add_neumann, double *__restrict__ out,
                                                               double *__restrict__ nws, int32_t *__restrict__ queue) {
@@ -387,7 +564,49 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
 
         const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
         double rr;
-        if constexpr (ROWS_IN_LANES) {
+        if constexpr (STRIPS) {
+            // ---- the dense problem in 16 x 4 tiles, panels of four reflectors through the matrix unit (strip_factor) ---------
+            static_assert(ROWS_IN_LANES && !GENERAL, "the strip form serves the two-coloured kinds");
+            constexpr int NQ = (Dm::TOTAL + 15) / 16, NCB = (NP + 1 + 3) / 4;
+            const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
+            double C[NQ][NCB];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                // (sjq: sj behind an opaque move, fresh per tile row -- otherwise the column arithmetic of all ten blocks is hoisted
+                //  out of the loop, ~60 lane constants that end up in scratch and come back one by one, each behind a full wait)
+                int sjq;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(sjq) : "v"(sj));
+                const int row = 16 * q + 4 * sb + si;
+                const bool fill = row < Dm::DROW0;
+                const int f = fill ? (row * 37) >> 8 : 0, i = row - 7 * f, d = row - Dm::DROW0;
+                const uint32_t q0w = (uint32_t)__shfl((int)w0l, f), q1w = (uint32_t)__shfl((int)w1l, f);
+                const int s0 = (q0w >> 11) & 15, s1 = (q1w >> 6) & 15, s2 = (q1w >> 22) & 15;   // dense slots of the front's 3 neighbours
+                const bool ok = fill ? f < F : d < D;
+                const int fbase = f * STAGE_F + i * 10;
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const int col = 4 * cb + sjq;
+                    const int sd = (col * 43) >> 7, tt = col - 3 * sd;                           // column = component tt of dense slot sd
+                    int off = Dm::LDS_Z;
+                    if (fill) {
+                        off = s0 == sd ? fbase + tt : off;
+                        off = s1 == sd ? fbase + 3 + tt : off;
+                        off = s2 == sd ? fbase + 6 + tt : off;
+                        off = col == nc ? fbase + 9 : off;
+                    } else {
+                        off = d == sd ? Dm::LDS_D + col : off;                                  // the cell row: (x_K - x_v) on its own columns
+                    }
+                    off = (ok && col <= nc) ? off : Dm::LDS_Z;
+                    double v = Rm[off];
+                    v = (!fill && ok && col == nc) ? 1.0 : v;                                   // a cell row's c entry
+                    C[q][cb] = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one tile row at a time: hoisted index arithmetic of six costs ~60 registers
+            }
+            wave_lds_sync();          // the staging area is R's from here on
+            NIN_MFW_STAMP(3);   // rows gathered
+            rr = strip_factor<NQ, NCB>(C, nc, lane, Rm, RP);
+        } else if constexpr (ROWS_IN_LANES) {
             // ---- the dense problem, lane = ROW.  TWO arrays (large): lane r holds row NP + r (r < NREG) in a[] and pivot row
             //      r (r < NP) in b[]; one array (small): lane r holds row r in b[], the pivot rows first --------------------------
             constexpr int TOTAL = Dm::TOTAL;
@@ -662,14 +881,16 @@ int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc
     const int64_t cap = (kind == 1 ? 3 : 2) * 256;   // persistent: the 4-wave workgroups that are resident (2 per CU at <= 256 registers, 3 at <= 168)
     if (blocks > cap) blocks = cap;
     const bool lane_columns = getenv("NIN_MFW_LANE_COLUMNS") != nullptr;   // A/B switch: the first form of the dense phase
-#define NIN_MFW_LAUNCH(FMX, DMX, RL, GEN)                                                                               \
-    hipLaunchKernelGGL((nin_gls_mfw_kernel<FMX, DMX, RL, GEN>), dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, \
+    const bool no_strips = getenv("NIN_MFW_NO_STRIPS") != nullptr;         // A/B switch: the row-lane form instead of the strip form
+#define NIN_MFW_LAUNCH(FMX, DMX, RL, GEN, ST)                                                                           \
+    hipLaunchKernelGGL((nin_gls_mfw_kernel<FMX, DMX, RL, GEN, ST>), dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, \
                        count, add_neumann, out, nws, queue)
-    if (kind == 2) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwWideDense, true, true);
-    else if (kind == 1 && lane_columns) NIN_MFW_LAUNCH(kMfwSmallFronts, kMfwSmallDense, false, false);
-    else if (kind == 1) NIN_MFW_LAUNCH(kMfwSmallFronts, kMfwSmallDense, true, false);
-    else if (lane_columns) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, false, false);
-    else NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, true, false);
+    if (kind == 2) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwWideDense, true, true, false);
+    else if (kind == 1 && lane_columns) NIN_MFW_LAUNCH(kMfwSmallFronts, kMfwSmallDense, false, false, false);
+    else if (kind == 1) NIN_MFW_LAUNCH(kMfwSmallFronts, kMfwSmallDense, true, false, false);
+    else if (lane_columns) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, false, false, false);
+    else if (no_strips) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, true, false, false);
+    else NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, true, false, true);
 #undef NIN_MFW_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -111,6 +111,76 @@ def house(alpha, S):
     return beta, alpha - beta, 1.0 / (S + abs(alpha) * sq)
 
 
+BLOCKED = False      # the dense problem: one reflector at a time (kernel form "lane = row") or in panels of four (the MFMA form)
+
+
+def dense_by_columns(C, nc):
+    """step t pivots on row t; one reduction per column (rows_step of kernels_gls_mfw.hip); returns r . r"""
+    live = np.ones(C.shape[0], dtype=bool)
+    dk = float(C[:, 0] @ C[:, 0])                  # the first column's norm; the later ones ride with the reductions
+    for t in range(nc):
+        alpha = C[t, t]
+        beta, vk, g = house(alpha, dk)
+        v = np.where(live, C[:, t], 0.0)
+        v[t] = vk
+        w = g * (v @ C[:, t + 1:])
+        C[:, t + 1:] -= np.outer(v, w)
+        C[t, t] = beta
+        live[t] = False
+        if t + 1 < nc:
+            dk = float(np.where(live, C[:, t + 1], 0.0) @ np.where(live, C[:, t + 1], 0.0))
+    return float(np.where(live, C[:, nc], 0.0) @ np.where(live, C[:, nc], 0.0))
+
+
+def dense_blocked(C, nc, nb=4):
+    """The same Householder QR in panels of nb = 4 columns (compact WY), the way the strip form of the kernel computes it:
+    panel p = columns 4 p .. 4 p + 3 (the last one may hold fewer pivot columns and then c, which sits at column nc),
+    pivot rows 4 p + k.  In the panel: d_j = sum over the rows BELOW the pivot of a[r][k] a[r][j] (one reduction for all
+    columns of the panel), the pivot row's entries separately, e_j = d_j + v_p a[p][j], w_j = -g e_j.  Then
+    T (upper triangular, H_0 .. H_3 = I - V T V^T): T[k][k] = g_k, T[0:k, k] = -g_k T[0:k, 0:k] (V^T v_k);
+    trailing columns: W = V^T C, W' = T^T W, C -= V W' -- the three products the matrix unit does.  Returns r . r."""
+    m = C.shape[0]
+    n_panels = (nc + nb - 1) // nb
+    for p in range(n_panels):
+        c0 = nb * p
+        steps = min(nb, nc - c0)
+        width = min(nb, nc + 1 - c0)               # columns of the panel block that exist (c may be one of them)
+        P = C[:, c0:c0 + width]                    # view
+        V = np.zeros((m, nb))
+        gk = np.zeros(nb)
+        for k in range(steps):
+            rp = c0 + k
+            below = np.arange(m) > rp
+            xk = np.where(below, P[:, k], 0.0)
+            d = xk @ P                             # d[j], j = 0 .. width - 1 (d[k] = |x|^2)
+            ap = P[rp].copy()
+            beta, vp, g = house(ap[k], ap[k] * ap[k] + d[k])
+            e = d + vp * ap
+            w = -g * e
+            w[:k + 1] = 0.0
+            vrow = xk.copy()
+            vrow[rp] = vp
+            P += np.outer(vrow, w)
+            P[rp, k] = beta
+            V[:, k] = vrow
+            gk[k] = g
+        G = V.T @ V
+        T = np.zeros((nb, nb))
+        for k in range(steps):
+            T[k, k] = gk[k]
+            if k:
+                T[:k, k] = -gk[k] * (T[:k, :k] @ G[:k, k])
+        if c0 + width < nc + 1:                    # trailing columns
+            Ct = C[:, c0 + width:nc + 1]
+            W = V.T @ Ct
+            Ct -= V @ (T.T @ W)
+        # (the kernel keeps v below the diagonal of the panel; R needs zeros there)
+        for k in range(steps):
+            C[c0 + k + 1:, c0 + k] = 0.0
+    tail = C[nc:, nc]
+    return float(tail @ tail)
+
+
 def node_weights(p, G, perm, dmag):
     eb, ee = G.esup_ptr[p], G.esup_ptr[p + 1]
     fb, fe = G.fsup_ptr[p], G.fsup_ptr[p + 1]
@@ -184,21 +254,10 @@ def node_weights(p, G, perm, dmag):
         r0 = 7 * F + D + 3 * q
         C[r0:r0 + 3, 3 * sa:3 * sa + 3] = -np.stack([Ka @ N, T, tj * U])
         C[r0:r0 + 3, 3 * sb:3 * sb + 3] = np.stack([Kb @ N, T, tj * U])
-    # ---- the dense problem: step t pivots on row t; one reduction per column
-    live = np.ones(C.shape[0], dtype=bool)
-    dk = float(C[:, 0] @ C[:, 0])                  # the first column's norm; the later ones ride with the reductions
-    for t in range(nc):
-        alpha = C[t, t]
-        beta, vk, g = house(alpha, dk)
-        v = np.where(live, C[:, t], 0.0)
-        v[t] = vk
-        w = g * (v @ C[:, t + 1:])
-        C[:, t + 1:] -= np.outer(v, w)
-        C[t, t] = beta
-        live[t] = False
-        if t + 1 < nc:
-            dk = float(np.where(live, C[:, t + 1], 0.0) @ np.where(live, C[:, t + 1], 0.0))
-    rr = float(np.where(live, C[:, nc], 0.0) @ np.where(live, C[:, nc], 0.0))
+    if BLOCKED:
+        rr = dense_blocked(C, nc)
+    else:
+        rr = dense_by_columns(C, nc)
     # ---- R y = (Q^T c)(0:nc): rows scaled by 1 / R(i, i), by columns
     R = C[:nc]
     ri = 1.0 / np.diag(R[:, :nc])
@@ -219,6 +278,10 @@ def node_weights(p, G, perm, dmag):
 
 
 def main():
+    global BLOCKED
+    if "--blocked" in sys.argv:
+        BLOCKED = True
+        sys.argv.remove("--blocked")
     kind = sys.argv[1] if len(sys.argv) > 1 else "tet"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     import ninpol_oracle as O
