@@ -75,7 +75,7 @@ struct MfwDims {
     static constexpr int LDS_FS = FM * STAGE_F;
     static constexpr int LDS_R = ((NP + PAD) * RP > STAGE ? (NP + PAD) * RP : STAGE);   // R rows; the staging area lies under them
     static constexpr int LDS_Y = LDS_R, LDS_D = LDS_Y + 3 * DM + 4, LDS_W = LDS_D + 3 * DM + 4, LDS_Z = LDS_W + FM + DM,
-                         LDS_PER_WAVE = LDS_Z + 64;   // (LDS_Z: 64 zeros, what a lane without an entry in a fill row reads)
+                         LDS_PER_WAVE = LDS_Z + 66;   // (LDS_Z: 64 zeros, what a lane without an entry in a fill row reads; then a one)
     static_assert(NREG > 0 && NP % 2 == 0 || ROWS_IN_LANES, "row split");
     static_assert(!GENERAL || (ROWS_IN_LANES && TOTAL <= 128 && NP <= 64 && FM * 4 + kMfwMaxFree <= 64 && 26 + kMfwMaxFree <= kMfwDescWords), "lanes");
 };
@@ -243,6 +243,13 @@ __device__ __forceinline__ void rows_block(double (&a)[NC], double (&b)[NC], dou
 // instruction), C -= V W' (one per row tile) -- against one 64-lane reduction and two v_readlane per COLUMN AND REFLECTOR in the
 // row-lane form.  Only the panel itself (4 columns) is factored by the vector unit, one reduction per step for all its columns.
 // After a panel the column blocks move down by one register, so one body serves every panel.
+#ifdef NIN_MFW_STAMPS
+struct SubStamps { unsigned long long last, acc[6]; bool on; };
+#define NIN_SUB(ST, J) do { if ((ST).on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); (ST).acc[J] += t_ - (ST).last; (ST).last = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+struct SubStamps { };
+#define NIN_SUB(ST, J) do { } while (0)
+#endif
 __device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 // sum over the four quads of a 16-lane row, in every quad
 __device__ __forceinline__ double sum_quads(double v) {
@@ -275,8 +282,11 @@ __device__ __forceinline__ void sum_rows2(double &a, double &b) {
 
 // One panel step K on the panel's tiles P[q], q >= Q0 (column block 0): pivot row rp = 4 p + K = (tile Q0, quad bp, i = K).
 // Tiles above Q0 hold rows below every pivot of this panel: no masks there.  vp[K], gk[K]: the reflector's pivot entry and scalar.
+// Tc[i] (i < K): on exit T[i][K] of the panel's triangular factor, T[0:K, K] = -g_K T[0:K, 0:K] (V^T v_K): the products
+// v_i . v_K (i < K) are the SAME sums as the step's own dots -- column i below the pivot still holds v_i -- so they come out of
+// the step's one reduction, in the lanes j = i.
 template <int NQ, int Q0, int K>
-__device__ __forceinline__ void strip_panel_step(double (&P)[NQ], double (&vp)[4], double (&gk)[4], int bp, int si, int sb, int sj) {
+__device__ __forceinline__ void strip_panel_step(double (&P)[NQ], double (&vp)[4], double (&gk)[4], double (&T)[4][4], int bp, int si, int sb, int sj) {
     const bool in_piv_quad = sb == bp;
     const bool is_piv = in_piv_quad && si == K;                  // this lane's row of tile Q0 is the pivot row
     const bool below0 = sb > bp || (in_piv_quad && si > K);      // ... lies below it
@@ -290,9 +300,24 @@ __device__ __forceinline__ void strip_panel_step(double (&P)[NQ], double (&vp)[4
     double d = sum_quads(acc), ap = sum_quads(is_piv ? P[Q0] : 0.0);   // (the pivot row's entry of column j, from its quad)
     sum_rows2(d, ap);
     const House h = house_unguarded(quad_pick<K>(ap), quad_pick<K>(d));
-    const double w = sj > K ? -(h.g * fma(h.vp, ap, d)) : 0.0;   // w_j = -g (v . a_j), the panel's later columns only
+    const double e = fma(h.vp, ap, d);                           // v_K . (column j): j > K the columns still to update, j < K v_j
+    const double w = sj > K ? -(h.g * e) : 0.0;                  // w_j = -g (v . a_j), the panel's later columns only
     gk[K] = h.g;
     vp[K] = h.vp;
+    T[K][K] = h.g;
+    if (K >= 1) {
+        double Gk[3];
+        Gk[0] = quad_pick<0>(e);
+        if (K >= 2) Gk[1] = quad_pick<1>(e);
+        if (K >= 3) Gk[2] = quad_pick<2>(e);
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double t = T[i][i] * Gk[i];
+#pragma unroll
+            for (int l = i + 1; l < K; ++l) t = fma(T[i][l], Gk[l], t);
+            T[i][K] = -(h.g * t);
+        }
+    }
 #pragma unroll
     for (int q = Q0; q < NQ; ++q) {
         double x = fma(w, q == Q0 && is_piv ? h.vp : xm[q], P[q]);
@@ -303,17 +328,18 @@ __device__ __forceinline__ void strip_panel_step(double (&P)[NQ], double (&vp)[4
 
 // Panel p (tiles Q0 .. NQ - 1; NT trailing column blocks at most): factor it, apply it, store its rows of R.
 template <int NQ, int NCB, int Q0, int NT>
-__device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc, int si, int sb, int sj, double eye, double *Rm, int RP) {
+__device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc, int si, int sb, int sj, double eye, double *Rm, int RP, SubStamps &ST) {
     const int bp = p & 3, steps = nc - 4 * p < 4 ? nc - 4 * p : 4;
     double V[NQ], gk[4] = {0.0, 0.0, 0.0, 0.0}, vp[4] = {0.0, 0.0, 0.0, 0.0};
+    double T[4][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     {
         double P[NQ];
 #pragma unroll
         for (int q = Q0; q < NQ; ++q) P[q] = C[q][0];
-        strip_panel_step<NQ, Q0, 0>(P, vp, gk, bp, si, sb, sj);
-        if (steps > 1) strip_panel_step<NQ, Q0, 1>(P, vp, gk, bp, si, sb, sj);
-        if (steps > 2) strip_panel_step<NQ, Q0, 2>(P, vp, gk, bp, si, sb, sj);
-        if (steps > 3) strip_panel_step<NQ, Q0, 3>(P, vp, gk, bp, si, sb, sj);
+        strip_panel_step<NQ, Q0, 0>(P, vp, gk, T, bp, si, sb, sj);
+        if (steps > 1) strip_panel_step<NQ, Q0, 1>(P, vp, gk, T, bp, si, sb, sj);
+        if (steps > 2) strip_panel_step<NQ, Q0, 2>(P, vp, gk, T, bp, si, sb, sj);
+        if (steps > 3) strip_panel_step<NQ, Q0, 3>(P, vp, gk, T, bp, si, sb, sj);
 #pragma unroll
         for (int q = Q0; q < NQ; ++q) { C[q][0] = P[q]; V[q] = P[q]; }
         // V: below the pivots the panel's columns ARE the reflectors; in the pivot quad the diagonal takes v's pivot entries,
@@ -328,23 +354,16 @@ __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc,
             for (int q = Q0; q < NQ; ++q) V[q] = sj < steps ? V[q] : 0.0;
         }
     }
+    NIN_SUB(ST, 0);   // panel factored
     if (NT > 0) {
-        // T: T[k][k] = g_k, T[0:k, k] = -g_k T[0:k, 0:k] (V^T v_k); G = V^T V by the matrix unit
-        double G = 0.0;
-#pragma unroll
-        for (int q = Q0; q < NQ; ++q) G = mfma4(V[q], V[q], G);
-        G = sum_quads(G);                                        // lane (i, ., j): G[i][j]
-        const double G01 = rl64(G, 1), G02 = rl64(G, 2), G03 = rl64(G, 3), G12 = rl64(G, 18), G13 = rl64(G, 19), G23 = rl64(G, 35);
-        const double T00 = gk[0], T11 = gk[1], T22 = gk[2], T33 = gk[3];
-        const double T01 = -T11 * (T00 * G01);
-        const double T02 = -T22 * fma(T01, G12, T00 * G02), T12 = -T22 * (T11 * G12);
-        const double T03 = -T33 * fma(T02, G23, fma(T01, G13, T00 * G03)), T13 = -T33 * fma(T12, G23, T11 * G13), T23 = -T33 * (T22 * G23);
+        // T (upper triangular: H_0 .. H_3 = I - V T V^T) came out of the steps; a step that did not run left its row and column zero
         // the strip T[k][i] at lane (k = si, ., i = sj); zero below the diagonal
         double Ts = 0.0;
-        Ts = si == 0 ? (sj == 0 ? T00 : sj == 1 ? T01 : sj == 2 ? T02 : T03) : Ts;
-        Ts = si == 1 ? (sj == 1 ? T11 : sj == 2 ? T12 : sj == 3 ? T13 : 0.0) : Ts;
-        Ts = si == 2 ? (sj == 2 ? T22 : sj == 3 ? T23 : 0.0) : Ts;
-        Ts = si == 3 ? (sj == 3 ? T33 : 0.0) : Ts;
+        Ts = si == 0 ? (sj == 0 ? T[0][0] : sj == 1 ? T[0][1] : sj == 2 ? T[0][2] : T[0][3]) : Ts;
+        Ts = si == 1 ? (sj == 1 ? T[1][1] : sj == 2 ? T[1][2] : sj == 3 ? T[1][3] : 0.0) : Ts;
+        Ts = si == 2 ? (sj == 2 ? T[2][2] : sj == 3 ? T[2][3] : 0.0) : Ts;
+        Ts = si == 3 ? (sj == 3 ? T[3][3] : 0.0) : Ts;
+        NIN_SUB(ST, 1);   // T
         // W[cb] = V^T C[.][cb]: NT independent accumulation chains (blocks past the live ones hold zeros: harmless)
         double W[NT + 1];
 #pragma unroll
@@ -358,6 +377,7 @@ __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc,
         for (int cb = 1; cb <= NT; ++cb) W[cb] = sum_quads(W[cb]);
 #pragma unroll
         for (int cb = 1; cb <= NT; ++cb) W[cb] = -mfma4(Ts, W[cb], 0.0);       // -(T^T W), the same in every quad
+        NIN_SUB(ST, 2);   // W, T^T W
         // C -= V W': the A operand is V^T per quad (one instruction with the identity transposes a tile)
 #pragma unroll
         for (int q = Q0; q < NQ; ++q) {
@@ -366,11 +386,16 @@ __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc,
             for (int cb = 1; cb <= NT; ++cb) C[q][cb] = mfma4(VT, W[cb], C[q][cb]);
         }
     }
+    NIN_SUB(ST, 3);   // update
     // rows 4 p .. 4 p + steps - 1 of R are final: tile Q0, quad bp
+    if (sb == bp && si < steps) {
+        const int col0 = 4 * p + sj;
+        double *dst = Rm + (4 * p + si) * RP + col0;
+        if (sj >= si && col0 <= nc) dst[0] = C[Q0][0];
 #pragma unroll
-    for (int cb = 0; cb <= NT; ++cb) {
-        const int col = 4 * (p + cb) + sj;
-        if (sb == bp && si < steps && col <= nc && (cb > 0 || sj >= si)) Rm[(4 * p + si) * RP + col] = C[Q0][cb];
+        for (int cb = 1; cb <= NT; ++cb) {
+            if (col0 + 4 * cb <= nc) dst[4 * cb] = C[Q0][cb];
+        }
     }
     if (steps == 4) {                                            // the next panel (or c) moves into block 0
 #pragma unroll
@@ -380,23 +405,24 @@ __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc,
             C[q][NT] = 0.0;
         }
     }
+    NIN_SUB(ST, 4);   // R stored, blocks shifted
 }
 
 // The whole dense factorisation.  On entry C[q][cb] = the tiles (c at column nc); on exit R's rows 0 .. nc - 1 (columns up to
 // nc = Q^T c) are in LDS at Rm[row * RP + col] and the return value is r . r = |(Q^T c)(nc:)|^2.  Panels 4 Q0 .. 4 Q0 + 3 pivot in
 // tile Q0; they have at most NCB - 1 - 4 Q0 trailing blocks (the first of them; the later ones sweep a few zero blocks too).
 template <int NQ, int NCB>
-__device__ __forceinline__ double strip_factor(double (&C)[NQ][NCB], int nc, int lane, double *Rm, int RP) {
+__device__ __forceinline__ double strip_factor(double (&C)[NQ][NCB], int nc, int lane, double *Rm, int RP, SubStamps &ST) {
     const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3, rowbase = 4 * sb + si;
     const double eye = si == sj ? 1.0 : 0.0;                     // the 4 x 4 identity in every quad
     const int n_panels = (nc + 3) >> 2;
     static_assert(NQ >= 3 && NCB <= 12, "three generations of panels");
-    for (int p = 0; p < (n_panels < 4 ? n_panels : 4); ++p) strip_panel<NQ, NCB, 0, NCB - 1>(C, p, nc, si, sb, sj, eye, Rm, RP);
+    for (int p = 0; p < (n_panels < 4 ? n_panels : 4); ++p) strip_panel<NQ, NCB, 0, NCB - 1>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
     if constexpr (NCB > 5) {
-        for (int p = 4; p < (n_panels < 8 ? n_panels : 8); ++p) strip_panel<NQ, NCB, 1, NCB - 5>(C, p, nc, si, sb, sj, eye, Rm, RP);
+        for (int p = 4; p < (n_panels < 8 ? n_panels : 8); ++p) strip_panel<NQ, NCB, 1, NCB - 5>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
     }
     if constexpr (NCB > 9) {
-        for (int p = 8; p < n_panels; ++p) strip_panel<NQ, NCB, 2, NCB - 9>(C, p, nc, si, sb, sj, eye, Rm, RP);
+        for (int p = 8; p < n_panels; ++p) strip_panel<NQ, NCB, 2, NCB - 9>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
     }
     // c sits in block 0, column nc & 3; r . r over the rows that never were pivot rows
     double t = 0.0;
@@ -422,6 +448,7 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts && !STRIPS ? 3 : 2)) vo
     double *const Rm = lds_all[threadIdx.x >> 6];
     double *const yb = Rm + Dm::LDS_Y, *const dbuf = Rm + Dm::LDS_D, *const wbuf = Rm + Dm::LDS_W;
     Rm[Dm::LDS_Z + lane] = 0.0;
+    if (lane == 0) Rm[Dm::LDS_Z + 64] = 1.0;
     const int sc = (lane * 43) >> 7, tc = lane - 3 * sc;          // this lane's dense column = component tc of dense slot sc
 
     auto ticket = [&]() -> int32_t {
@@ -570,42 +597,60 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts && !STRIPS ? 3 : 2)) vo
             constexpr int NQ = (Dm::TOTAL + 15) / 16, NCB = (NP + 1 + 3) / 4;
             const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
             double C[NQ][NCB];
+            // per tile row: where this lane's row lives in the staging area.  code(sd) = 1 + the index of dense slot sd among
+            // the front's three neighbours (0: not a neighbour), two bits per slot, made once per front (lane f) and shuffled
+            uint32_t tbl = 0;
+            {
+                const int s0 = (w0l >> 11) & 15, s1 = (w1l >> 6) & 15, s2 = (w1l >> 22) & 15;
+                tbl = (1u << (2 * s0)) | (2u << (2 * s1)) | (3u << (2 * s2));
+                tbl = lane < F ? tbl : 0u;
+            }
+            int rbase[NQ];          // LDS index of the row's first staged entry (fill rows), -1 - d for the cell row of dense cell d, big = no row
+            uint32_t rtbl[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                // (sjq: sj behind an opaque move, fresh per tile row -- otherwise the column arithmetic of all ten blocks is hoisted
-                //  out of the loop, ~60 lane constants that end up in scratch and come back one by one, each behind a full wait)
-                int sjq;
-                asm volatile("v_mov_b32 %0, %1" : "=v"(sjq) : "v"(sj));
                 const int row = 16 * q + 4 * sb + si;
                 const bool fill = row < Dm::DROW0;
                 const int f = fill ? (row * 37) >> 8 : 0, i = row - 7 * f, d = row - Dm::DROW0;
-                const uint32_t q0w = (uint32_t)__shfl((int)w0l, f), q1w = (uint32_t)__shfl((int)w1l, f);
-                const int s0 = (q0w >> 11) & 15, s1 = (q1w >> 6) & 15, s2 = (q1w >> 22) & 15;   // dense slots of the front's 3 neighbours
-                const bool ok = fill ? f < F : d < D;
-                const int fbase = f * STAGE_F + i * 10;
+                rtbl[q] = (uint32_t)__shfl((int)tbl, f);
+                rtbl[q] = fill ? rtbl[q] : 0u;
+                rbase[q] = fill ? (f < F ? f * STAGE_F + i * 10 : 1 << 20) : (d < D ? -1 - d : 1 << 20);
+            }
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    const int col = 4 * cb + sjq;
-                    const int sd = (col * 43) >> 7, tt = col - 3 * sd;                           // column = component tt of dense slot sd
-                    int off = Dm::LDS_Z;
-                    if (fill) {
-                        off = s0 == sd ? fbase + tt : off;
-                        off = s1 == sd ? fbase + 3 + tt : off;
-                        off = s2 == sd ? fbase + 6 + tt : off;
-                        off = col == nc ? fbase + 9 : off;
-                    } else {
-                        off = d == sd ? Dm::LDS_D + col : off;                                  // the cell row: (x_K - x_v) on its own columns
+            for (int cb = 0; cb < NCB; ++cb) {
+                // (sjq: sj behind an opaque move, fresh per column block -- otherwise the column arithmetic of all ten blocks is
+                //  hoisted, ~60 lane constants that end up in scratch and come back one by one, each behind a full wait)
+                int sjq;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(sjq) : "v"(sj));
+                const int col = 4 * cb + sjq;
+                const int sd = (col * 43) >> 7, tt = col - 3 * sd;                               // column = component tt of dense slot sd
+                const bool is_c = col == nc, past = col > nc;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int rb = rbase[q];
+                    const uint32_t code = (rtbl[q] >> (2 * sd)) & 3u;
+                    int off = code ? rb + 3 * (int)code - 3 + tt : Dm::LDS_Z;
+                    off = is_c ? rb + 9 : off;
+                    if (16 * q + 15 >= Dm::DROW0) {                                             // tiles that hold cell rows
+                        const bool cell = rb < 0;
+                        off = cell ? ((-1 - rb) == sd && !is_c ? Dm::LDS_D + col : Dm::LDS_Z) : off;
+                        off = (cell && is_c) ? Dm::LDS_Z + 64 : off;                            // (the slot behind the zeros holds a one)
                     }
-                    off = (ok && col <= nc) ? off : Dm::LDS_Z;
-                    double v = Rm[off];
-                    v = (!fill && ok && col == nc) ? 1.0 : v;                                   // a cell row's c entry
-                    C[q][cb] = v;
+                    off = (past || rb >= (1 << 20)) ? Dm::LDS_Z : off;
+                    C[q][cb] = Rm[off];
                 }
-                __builtin_amdgcn_sched_barrier(0);   // one tile row at a time: hoisted index arithmetic of six costs ~60 registers
             }
             wave_lds_sync();          // the staging area is R's from here on
             NIN_MFW_STAMP(3);   // rows gathered
-            rr = strip_factor<NQ, NCB>(C, nc, lane, Rm, RP);
+            SubStamps ST;
+#ifdef NIN_MFW_STAMPS
+            ST.on = stamping; ST.last = __builtin_amdgcn_s_memtime();
+            for (int j = 0; j < 6; ++j) ST.acc[j] = 0;
+#endif
+            rr = strip_factor<NQ, NCB>(C, nc, lane, Rm, RP, ST);
+#ifdef NIN_MFW_STAMPS
+            if (stamping && lane == 0) for (int j = 0; j < 5; ++j) nws[nodes[8 + j]] = (double)ST.acc[j];
+#endif
         } else if constexpr (ROWS_IN_LANES) {
             // ---- the dense problem, lane = ROW.  TWO arrays (large): lane r holds row NP + r (r < NREG) in a[] and pivot row
             //      r (r < NP) in b[]; one array (small): lane r holds row r in b[], the pivot rows first --------------------------
@@ -802,12 +847,26 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts && !STRIPS ? 3 : 2)) vo
             const int li = lane < nc ? lane : 0;
             double ct = lane < nc ? Rm[li * RP + nc] : 0.0;
             const double ri = fast_rcp(Rm[li * RP + li]);
-            double coln = lane < nc ? Rm[li * RP + (nc - 1)] : 0.0;
-            for (int k = nc - 1; k >= 0; --k) {
-                const double col = lane <= k ? coln : 0.0;
-                if (k > 0) coln = lane < nc ? Rm[li * RP + (k - 1)] : 0.0;
-                const double yk = rl64(ct * ri, k);
-                ct = lane < k ? fma(-yk, col, ct) : ct;
+            // four columns per round, the next round's four loaded before this round's dependent chain (y_k: one product, one
+            // broadcast, one FMA per column) starts: the loop was one LDS round trip per column (36 of them: 10 k cycles a node)
+            const double *Rl = Rm + li * RP;
+            int kb = (nc - 1) & ~3;
+            double c4[4], n4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c4[j] = (lane < nc && kb + j < nc) ? Rl[kb + j] : 0.0;
+            for (; kb >= 0; kb -= 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) n4[j] = (lane < nc && kb >= 4) ? Rl[kb - 4 + j] : 0.0;
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const int k = kb + j;
+                    if (k < nc) {                                             // (wave-uniform: only the first round can be short)
+                        const double yk = rl64(ct * ri, k);
+                        ct = lane < k ? fma(-yk, c4[j], ct) : ct;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c4[j] = n4[j];
             }
             if (lane < nc) yb[lane] = ct * ri;
         }

@@ -18,3 +18,9 @@ print("one Kuhn-tet node, wavefront 0 of workgroup 0, its 5th node (cycles):")
 for i, n in enumerate(names):
     print(f"  {n:36s} {st[i + 1] - st[i]:8.0f}")
 print(f"  {'node':36s} {st[6]:8.0f}")
+
+sub = np.asarray(nws)[np.nonzero((ne == 24) & ~bp)[0][8:13]]
+if sub.sum() > 0 and sub.max() < 1e9:
+    print("  inside the dense factorisation (strip form), summed over the panels:")
+    for n, v in zip(["panels factored (4 columns each, vector unit)", "T", "W = V^T C, T^T W", "C -= V W'", "rows of R stored, blocks shifted"], sub):
+        print(f"    {n:48s} {v:8.0f}")
