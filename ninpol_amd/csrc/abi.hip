@@ -346,6 +346,13 @@ int nin_grid_to_device(nin_grid *g, int device) {
         if ((rc = dev_alloc(d, &dm, (size_t)E))) return rc;
         v.perm = perm; v.diff_mag = dm;
     }
+    v.centroids4 = nullptr;
+    if (getenv("NIN_ROWS_PAD4") != nullptr) {   // experiment: (x, y, z, 0) per cell, a centroid in two 16-byte loads -- 3 % SLOWER than the packed array
+        double *c4 = nullptr;
+        if ((rc = dev_alloc(d, &c4, (size_t)E * 4))) return rc;
+        if (launch_pad_centroids(v.centroids, E, c4, nullptr)) return fail(NIN_EHIP, "centroid padding kernel");
+        v.centroids4 = c4;
+    }
     // ---- GLS launch plan: bin nodes by the size of their least-squares system (classified on the device) ----
     g->node_class.assign((size_t)P, 0);
     std::vector<std::vector<int32_t>> lists(kGlsClasses);

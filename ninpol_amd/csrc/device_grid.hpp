@@ -19,6 +19,7 @@ struct GridView {  // passed to kernels by value
     const int32_t *fsup;       // [nnz_f]   faces around node, ascending
     const double *coords;      // [P][3]
     const double *centroids;   // [E][3]
+    const double *centroids4;  // [E][4] = (x, y, z, 0): one 32-byte record per cell for the IDW / LS gathers (null unless NIN_ROWS_PAD4: measured slower)
     const int32_t *face_cells; // [F][2]    esuf pair, second = -1 on a boundary face
     const double *face_center; // [F][3]
     const float *face_normal;  // [F][3]

@@ -76,6 +76,12 @@ __global__ __launch_bounds__(256) void nin_apply_fields_kernel(GridView g, const
     }
 }
 
+__global__ __launch_bounds__(256) void nin_pad_centroids_kernel(const double *__restrict__ src, int64_t n, double *__restrict__ dst) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        dst[4 * e + 0] = src[3 * e + 0]; dst[4 * e + 1] = src[3 * e + 1]; dst[4 * e + 2] = src[3 * e + 2]; dst[4 * e + 3] = 0.0;
+    }
+}
+
 int grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -91,6 +97,12 @@ int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipS
 int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr, int32_t *indices,
                    double *vals, hipStream_t stream) {
     hipLaunchKernelGGL(nin_compact_kernel, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, new_ptr, indices, vals);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_pad_centroids(const double *src, int64_t n_elems, double *dst, hipStream_t stream) {
+    if (n_elems <= 0) return 0;
+    hipLaunchKernelGGL(nin_pad_centroids_kernel, dim3(grid_for(n_elems)), dim3(256), 0, stream, src, n_elems, dst);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -33,6 +33,18 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// a cell's centroid: from the padded [E][4] copy when the grid carries one (two 16-byte loads, one 64-byte line), else
+// from the packed [E][3] array (three 8-byte loads, 37 % of the records straddle two lines)
+__device__ __forceinline__ void load_centroid(const GridView &g, size_t s, double (&c)[3]) {
+    if (g.centroids4) {
+        const double2 xy = *reinterpret_cast<const double2 *>(g.centroids4 + 4 * s);
+        c[0] = xy.x; c[1] = xy.y;
+        c[2] = g.centroids4[4 * s + 2];
+    } else {
+        c[0] = g.centroids[3 * s + 0]; c[1] = g.centroids[3 * s + 1]; c[2] = g.centroids[3 * s + 2];
+    }
+}
+
 // idw.pyx:35-84 for one node.  cells / w: the node's row (LDS).  `machine_epsilon` is the C float
 // (float)1e-15 compared against the SQUARED distance (idw.pyx:53,67-69); distances use the first `dim`
 // coordinates (idw.pyx:66).
@@ -47,10 +59,7 @@ __device__ __forceinline__ void idw_row(const GridView &g, int32_t p, const int3
         double c[8][3];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const size_t s = (size_t)cells[j0 + u < n ? j0 + u : n - 1];
-            c[u][0] = g.centroids[3 * s + 0];
-            c[u][1] = g.centroids[3 * s + 1];
-            c[u][2] = g.centroids[3 * s + 2];
+            load_centroid(g, (size_t)cells[j0 + u < n ? j0 + u : n - 1], c[u]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -88,10 +97,7 @@ __device__ __forceinline__ void ls_row(const GridView &g, int32_t p, const int32
         double c[8][3];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {   // 8 centroid gathers in flight, then the reference's sequential sums
-            const size_t s = (size_t)cells[j0 + u < n ? j0 + u : n - 1];
-            c[u][0] = g.centroids[3 * s + 0];
-            c[u][1] = g.centroids[3 * s + 1];
-            c[u][2] = g.centroids[3 * s + 2];
+            load_centroid(g, (size_t)cells[j0 + u < n ? j0 + u : n - 1], c[u]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {

@@ -52,6 +52,8 @@ int launch_apply_fields(const GridView &g, const double *data, const double *u, 
 
 // GLS launch plan (grid_device.hip): size class of every node (255 = the hex8 kernel, 254 / 253 / 252 = the one-wavefront multifrontal kernel: two-coloured nodes large / small, general kind) and, per class, the
 // maxima of (bytes, rows, columns) as 3 * kGlsClasses unsigned 64-bit values; all DEVICE pointers
+// kernels_csr.hip: dst[e] = (src[3 e], src[3 e + 1], src[3 e + 2], 0)
+int launch_pad_centroids(const double *src, int64_t n_elems, double *dst, hipStream_t stream);
 int launch_classify(const GridView &g, int use_group, int force_global, uint8_t *node_class,
                     unsigned long long *class_max, hipStream_t stream);
 

@@ -16,8 +16,12 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-__device__ __forceinline__ uint32_t mix(uint32_t x) {   // bijection on 32 bits: a permutation of the line indices
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+// a permutation of [0, 2^k) for every k: multiplication by an odd constant is a bijection modulo any power of two (the
+// caller masks), and the xor-shift folds the high bits of the product down so neighbours do not land in neighbouring lines
+__device__ __forceinline__ uint32_t mix(uint32_t x, uint32_t mask) {
+    x = (x * 0x9E3779B1u) & mask;
+    x ^= x >> 7;            // (bijective on the masked range: a unit upper-triangular GF(2) map)
+    x = (x * 0x85EBCA6Bu) & mask;
     return x;
 }
 
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(256) void gather8(const char *__restrict__ src, uin
                                                 double *__restrict__ sink) {
     double acc = 0.0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < lanes; t += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t line = mix((uint32_t)t) & (n_lines - 1);
+        const uint32_t line = mix((uint32_t)t, n_lines - 1);
         acc += *(const double *)(src + ((size_t)line << line_shift));
     }
     if (acc == 1.2345e-300) sink[0] = acc;
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void gather24(const double *__restrict__ src, 
                                                  double *__restrict__ sink) {
     double acc = 0.0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < lanes; t += (size_t)gridDim.x * blockDim.x) {
-        const size_t c = mix((uint32_t)t) & (n_cells_pow2 - 1);
+        const size_t c = mix((uint32_t)t, n_cells_pow2 - 1);
         acc += src[3 * c] + src[3 * c + 1] + src[3 * c + 2];
     }
     if (acc == 1.2345e-300) sink[0] = acc;
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void gather16_rows(const char *__restrict__ sr
                                                       double *__restrict__ sink) {
     double acc = 0.0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < lanes; t += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t line = mix((uint32_t)(t >> 2)) & (n_lines - 1);
+        const uint32_t line = mix((uint32_t)(t >> 2), n_lines - 1);
         const uint4 v = *(const uint4 *)(src + ((size_t)line << 6) + ((t & 3) << 4));
         acc += (double)v.x;
     }
@@ -86,6 +90,7 @@ int main() {
         CHECK(hipEventElapsedTime(&ms, a, b));
         printf("%-16s known %10.1f MiB  %.3f ms  %.0f GB/s\n", name, known_bytes / 1048576.0, ms, known_bytes / ms / 1e6);
     };
+    timed("(warm-up)", (double)bytes, [&] { hipLaunchKernelGGL(stream<uint2>, grid, 256, 0, 0, (const uint2 *)buf, bytes / 8, sink); });
     timed("stream16", (double)bytes, [&] { hipLaunchKernelGGL(stream<uint4>, grid, 256, 0, 0, (const uint4 *)buf, bytes / 16, sink); });
     timed("stream8", (double)bytes, [&] { hipLaunchKernelGGL(stream<uint2>, grid, 256, 0, 0, (const uint2 *)buf, bytes / 8, sink); });
     timed("stream4", (double)bytes, [&] { hipLaunchKernelGGL(stream<uint32_t>, grid, 256, 0, 0, (const uint32_t *)buf, bytes / 4, sink); });
@@ -96,5 +101,6 @@ int main() {
     const uint32_t cells = 1u << 26;   // 64 Mi cells x 24 B = 1.5 GiB, each read once
     timed("gather24", (double)cells * 24, [&] { hipLaunchKernelGGL(gather24, grid, 256, 0, 0, (const double *)buf, cells, (size_t)cells, sink); });
     timed("gather16_rows", (double)l64 * 64, [&] { hipLaunchKernelGGL(gather16_rows, grid, 256, 0, 0, buf, l64, (size_t)l64 * 4, sink); });
+    timed("stream16 again", (double)bytes, [&] { hipLaunchKernelGGL(stream<uint4>, grid, 256, 0, 0, (const uint4 *)buf, bytes / 16, sink); });
     return 0;
 }

@@ -1,21 +1,24 @@
 #!/bin/bash
-# PMC passes over the GLS kernels of one mesh family (default tet40): instruction mix and wait cycles.
+# Issue-side counters of the one-wavefront multifrontal kernel on the Kuhn-tet mesh: bash tools/pmc_tet.sh [out dir]
+# (two --pmc passes, kernel-trace only; SQ counters are per XCD-sampled: ratios matter, not absolutes)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=${1:-$R/gpurun_out/pmc_tet}
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-CASE=${1:-tet40}
+cd $R
 i=0
-for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA" "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_INSTS_SMEM"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" \
+           "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_WAIT_ANY"; do
   i=$((i+1))
-  (cd $R && timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_$CASE/p$i --output-format csv -- python3 tools/time_methods.py $CASE > $R/gpurun_out/pmc_$CASE/log$i.txt 2>&1) || { echo "pass $i failed"; tail -5 $R/gpurun_out/pmc_$CASE/log$i.txt; }
+  NIN_METHODS=gls timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 tools/time_methods.py tet40 > $OUT/p$i.txt 2> $OUT/p$i.err || { echo "pass $i failed"; tail -5 $OUT/p$i.err; exit 1; }
 done
-python3 - <<PY
-import csv, glob, collections
-for f in sorted(glob.glob("$R/gpurun_out/pmc_$CASE/p*/**/*counter_collection.csv", recursive=True)):
-    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+python3 - $OUT <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(list)
+for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:60]
-        if "gls" not in k: continue
-        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-    for k, d in acc.items():
-        print(k, {a: f"{b:.4g}" for a, b in d.items()})
+        k = r["Kernel_Name"]
+        if "nin_gls_mfw" in k: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for c, v in sorted(acc.items()): print(f"{c:34s} {len(v):3d} dispatches, average {sum(v) / len(v):16.1f}")
 PY
