@@ -338,13 +338,14 @@ def main():
         value = total_nodes * args.steps / elapsed / 1e6
         B_alg = plan.algorithmic_bytes
         ach = B_alg / (kern_ms * 1e-3) / 1e9
-        traffic = None   # PMC bytes per launch, only if recorded for exactly these kernel sources
+        traffic = traffic_bounds = None   # PMC bytes per launch, only if recorded for exactly these kernel sources
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("kernel_source_sha16") == kernel_source_hash():
                     traffic = tj.get(f"{args.method}_n{n}_bytes_per_launch")
+                    traffic_bounds = tj.get(f"{args.method}_n{n}_bounds")
             except Exception:
                 traffic = None
         hbm = {"achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
@@ -363,7 +364,7 @@ def main():
                     "hbm": hbm, "hbm_frac": hbm["frac"]}
         else:
             roof = dict(hbm, bound="hbm")
-        roof.update({"traffic": traffic, "kernel": plan.kernel_name, "kernel_ms": round(kern_ms, 4),
+        roof.update({"traffic": traffic, "traffic_bounds": traffic_bounds, "kernel": plan.kernel_name, "kernel_ms": round(kern_ms, 4),
                      "algorithmic_bytes_per_launch": B_alg, "bytes_per_node": round(B_alg / P_loc, 1)})
         line = {
             "metric": "Mnodes/s interpolated (GLS, 10M-cell hex mesh) + achieved HBM GB/s vs peak"

@@ -4,7 +4,7 @@
 # Pass 1: --kernel-trace --stats of the default bench (no CPU-baseline leg).  Passes 2-4: separate --pmc runs
 # (FETCH_SIZE; WRITE_SIZE; SQ counters), never combined with other trace domains.
 set -u
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
@@ -18,8 +18,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
 done
 # the block kernel by size class on the mixed and Kuhn-tet meshes (BASELINE config [3] at size: mixed10m)
 NIN_GRID_BUILD=device timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mixed_tet -- python3 tools/time_methods.py mixed tet40 wedge60 mixed10m > $OUT/methods_by_mesh.txt 2> $OUT/mixed_tet.err || { echo "mixed/tet pass failed"; tail -5 $OUT/mixed_tet.err; }
-# issue-side counters of the one-wavefront multifrontal kernel on the Kuhn-tet mesh (the instruction cache matters there)
-NIN_METHODS=gls timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IFETCH --output-format csv -d $OUT/pmc_tet -- python3 tools/time_methods.py tet40 > $OUT/pmc_tet.txt 2> $OUT/pmc_tet.err || { echo "tet pmc pass failed"; tail -5 $OUT/pmc_tet.err; }
+# issue-side counters of the one-wavefront multifrontal kernel on the Kuhn-tet mesh: the strip form and the row-lane form
+bash tools/pmc_tet.sh $OUT/pmc_tet_strips > $OUT/pmc_tet_strips.txt 2>&1 || echo "tet pmc (strips) failed"
+NIN_MFW_NO_STRIPS=1 bash tools/pmc_tet.sh $OUT/pmc_tet_rows > $OUT/pmc_tet_rows.txt 2>&1 || echo "tet pmc (rows) failed"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, json, collections, os
 out = sys.argv[1]
@@ -54,8 +55,15 @@ def traffic(prefixes):   # bytes per launch: 2 x FETCH (gfx950 correction, MI355
     return int(t)
 sys.path.insert(0, os.getcwd())
 import bench
+def traffic_lo(prefixes):   # the same with FETCH_SIZE taken as it reads: the lower bound when the reads are scattered gathers
+    t = 0.0
+    for (k, c), v in avg.items():
+        if any(k.startswith(p) for p in prefixes): t += v * 1024 * (1 if c in ("FETCH_SIZE", "WRITE_SIZE") else 0)
+    return int(t)
 tj = {"kernel_source_sha16": bench.kernel_source_hash(),
-      "note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section: gfx950 tallies 128-B requests at 64 B). pmc_summary.csv of the round holds the raw counters.",
+      "note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section: gfx950 tallies 128-B requests at 64 B). That rule is calibrated for coalesced streams; tools/micro_fetch.hip (profiles/r03/micro_fetch.txt) confirms it for 4 / 8 / 16 B per lane and shows that scattered gathers read anywhere between 0.5 and 2.3 of the bytes they use, so for the GLS kernels (4-16 B gathers) the doubled figure is the guide's prescription and *_bounds = [FETCH as read + WRITE, 2 FETCH + WRITE] brackets it. pmc_summary.csv of the round holds the raw counters.",
+      "gls_n216_bounds": [traffic_lo(["nin_gls_"]), traffic(["nin_gls_"])],
+      "idw_n216_bounds": [traffic_lo(["nin_rows_kernel<0>"]), traffic(["nin_rows_kernel<0>"])],
       "gls_n216_bytes_per_launch": traffic(["nin_gls_"]),
       "idw_n216_bytes_per_launch": traffic(["nin_rows_kernel<0>"]),   # kernels_idw_ls.hip: METHOD 0 = IDW, 1 = LS
       "ls_n216_bytes_per_launch": traffic(["nin_rows_kernel<1>"])}
