@@ -40,7 +40,7 @@ if mt:
     with open(out + "/kernel_stats_mixed_tet.csv", "w", newline="") as f:
         csv.writer(f, quoting=csv.QUOTE_ALL).writerows([r for r in csv.reader(open(mt[0]))])
 acc = collections.defaultdict(list)
-for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(out + "/pmc[0-9]/**/*counter_collection.csv", recursive=True) + glob.glob(out + "/pmc_tet_*/p[0-9]/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         if k.startswith("nin_"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
