@@ -355,14 +355,20 @@ __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc,
         }
     }
     NIN_SUB(ST, 0);   // panel factored
-    if (NT > 0) {
-        // T (upper triangular: H_0 .. H_3 = I - V T V^T) came out of the steps; a step that did not run left its row and column zero
-        // the strip T[k][i] at lane (k = si, ., i = sj); zero below the diagonal
+    // rows 4 p .. 4 p + steps - 1 of R are final after this panel: tile Q0, quad bp.  The panel block's own entries now:
+    const bool r_rows = sb == bp && si < steps;
+    const int col0 = 4 * p + sj;
+    double *dst = Rm + (4 * p + si) * RP + col0;
+    if (r_rows && sj >= si && col0 <= nc) dst[0] = C[Q0][0];
+    // (a panel with fewer than four pivots is the last one: c sits in its block, nothing lies to the right of it)
+    if (NT > 0 && steps == 4) {
+        // T (upper triangular: H_0 .. H_3 = I - V T V^T) came out of the steps; as a strip, negated: -T[k][i] at lane (k = si, ., i = sj)
         double Ts = 0.0;
         Ts = si == 0 ? (sj == 0 ? T[0][0] : sj == 1 ? T[0][1] : sj == 2 ? T[0][2] : T[0][3]) : Ts;
         Ts = si == 1 ? (sj == 1 ? T[1][1] : sj == 2 ? T[1][2] : sj == 3 ? T[1][3] : 0.0) : Ts;
         Ts = si == 2 ? (sj == 2 ? T[2][2] : sj == 3 ? T[2][3] : 0.0) : Ts;
         Ts = si == 3 ? (sj == 3 ? T[3][3] : 0.0) : Ts;
+        Ts = -Ts;
         NIN_SUB(ST, 1);   // T
         // W[cb] = V^T C[.][cb]: NT independent accumulation chains (blocks past the live ones hold zeros: harmless)
         double W[NT + 1];
@@ -376,36 +382,27 @@ __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc,
 #pragma unroll
         for (int cb = 1; cb <= NT; ++cb) W[cb] = sum_quads(W[cb]);
 #pragma unroll
-        for (int cb = 1; cb <= NT; ++cb) W[cb] = -mfma4(Ts, W[cb], 0.0);       // -(T^T W), the same in every quad
+        for (int cb = 1; cb <= NT; ++cb) W[cb] = mfma4(Ts, W[cb], 0.0);        // -(T^T W), the same in every quad
         NIN_SUB(ST, 2);   // W, T^T W
-        // C -= V W': the A operand is V^T per quad (one instruction with the identity transposes a tile)
+        // C -= V W': the A operand is V^T per quad (one instruction with the identity transposes a tile).  The result goes
+        // ONE BLOCK DOWN -- the next panel (or c) lands in block 0 without a single move; tiles above Q0 hold rows of R that
+        // are already in LDS and are never read again
 #pragma unroll
         for (int q = Q0; q < NQ; ++q) {
             const double VT = mfma4(V[q], eye, 0.0);
 #pragma unroll
-            for (int cb = 1; cb <= NT; ++cb) C[q][cb] = mfma4(VT, W[cb], C[q][cb]);
-        }
-    }
-    NIN_SUB(ST, 3);   // update
-    // rows 4 p .. 4 p + steps - 1 of R are final: tile Q0, quad bp
-    if (sb == bp && si < steps) {
-        const int col0 = 4 * p + sj;
-        double *dst = Rm + (4 * p + si) * RP + col0;
-        if (sj >= si && col0 <= nc) dst[0] = C[Q0][0];
-#pragma unroll
-        for (int cb = 1; cb <= NT; ++cb) {
-            if (col0 + 4 * cb <= nc) dst[4 * cb] = C[Q0][cb];
-        }
-    }
-    if (steps == 4) {                                            // the next panel (or c) moves into block 0
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-            for (int cb = 0; cb < NT; ++cb) C[q][cb] = C[q][cb + 1];
+            for (int cb = 1; cb <= NT; ++cb) C[q][cb - 1] = mfma4(VT, W[cb], C[q][cb]);
             C[q][NT] = 0.0;
         }
+        NIN_SUB(ST, 3);   // update
+        if (r_rows) {
+#pragma unroll
+            for (int cb = 1; cb <= NT; ++cb) {
+                if (col0 + 4 * cb <= nc) dst[4 * cb] = C[Q0][cb - 1];
+            }
+        }
     }
-    NIN_SUB(ST, 4);   // R stored, blocks shifted
+    NIN_SUB(ST, 4);   // rows of R stored
 }
 
 // The whole dense factorisation.  On entry C[q][cb] = the tiles (c at column nc); on exit R's rows 0 .. nc - 1 (columns up to
@@ -605,16 +602,22 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts && !STRIPS ? 3 : 2)) vo
                 tbl = (1u << (2 * s0)) | (2u << (2 * s1)) | (3u << (2 * s2));
                 tbl = lane < F ? tbl : 0u;
             }
-            int rbase[NQ];          // LDS index of the row's first staged entry (fill rows), -1 - d for the cell row of dense cell d, big = no row
+            // per tile row q, this lane's row of the dense problem: rtbl = the 2-bit codes of its non-zero column slots, rb = the LDS
+            // index of the entry code 1 points at (slot code c lies 3 (c - 1) further on), rbc = where its c entry is.  A fill row
+            // of front f: the front's table, its staged row, that row's 10th entry.  The cell row of dense cell d: code 1 at slot
+            // d only, (x_K - x_v) in dbuf, a one.  No row: no codes, zeros.
+            int rb[NQ], rbc[NQ];
             uint32_t rtbl[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int row = 16 * q + 4 * sb + si;
                 const bool fill = row < Dm::DROW0;
                 const int f = fill ? (row * 37) >> 8 : 0, i = row - 7 * f, d = row - Dm::DROW0;
-                rtbl[q] = (uint32_t)__shfl((int)tbl, f);
-                rtbl[q] = fill ? rtbl[q] : 0u;
-                rbase[q] = fill ? (f < F ? f * STAGE_F + i * 10 : 1 << 20) : (d < D ? -1 - d : 1 << 20);
+                const uint32_t ft = (uint32_t)__shfl((int)tbl, f);
+                const bool ok = fill ? f < F : d < D;
+                rtbl[q] = ok ? (fill ? ft : 1u << (2 * d)) : 0u;
+                rb[q] = fill ? f * STAGE_F + i * 10 : Dm::LDS_D + 3 * d;
+                rbc[q] = ok ? (fill ? rb[q] + 9 : Dm::LDS_Z + 64) : Dm::LDS_Z;
             }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
@@ -623,20 +626,14 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts && !STRIPS ? 3 : 2)) vo
                 int sjq;
                 asm volatile("v_mov_b32 %0, %1" : "=v"(sjq) : "v"(sj));
                 const int col = 4 * cb + sjq;
-                const int sd = (col * 43) >> 7, tt = col - 3 * sd;                               // column = component tt of dense slot sd
-                const bool is_c = col == nc, past = col > nc;
+                const int sd = (col * 43) >> 7, tt3 = col - 3 * sd - 3;                          // column = component tt of dense slot sd
+                const bool is_c = col == nc;
+                const int sh = col < nc ? 2 * sd : 30;                                          // (slot 15: nobody's neighbour)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int rb = rbase[q];
-                    const uint32_t code = (rtbl[q] >> (2 * sd)) & 3u;
-                    int off = code ? rb + 3 * (int)code - 3 + tt : Dm::LDS_Z;
-                    off = is_c ? rb + 9 : off;
-                    if (16 * q + 15 >= Dm::DROW0) {                                             // tiles that hold cell rows
-                        const bool cell = rb < 0;
-                        off = cell ? ((-1 - rb) == sd && !is_c ? Dm::LDS_D + col : Dm::LDS_Z) : off;
-                        off = (cell && is_c) ? Dm::LDS_Z + 64 : off;                            // (the slot behind the zeros holds a one)
-                    }
-                    off = (past || rb >= (1 << 20)) ? Dm::LDS_Z : off;
+                    const int code = (int)((rtbl[q] >> sh) & 3u);
+                    int off = code ? rb[q] + 3 * code + tt3 : Dm::LDS_Z;
+                    off = is_c ? rbc[q] : off;
                     C[q][cb] = Rm[off];
                 }
             }
