@@ -419,9 +419,40 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
     volatile int32_t *slot = reinterpret_cast<volatile int32_t *>(smem);
     double *const sys_lds = smem + 2;
     int within = 0;
+    // NW == 1: the wave looks at 64 list entries at a time, one per lane -- Dirichlet boundary nodes (gls.pyx:165-166; on
+    // an all-Dirichlet hexahedron mesh every node of this class: 280 k of them at 216^3) get their zero row right there, the
+    // others are taken one after the other.  (One node per wave and round cost 0.14 ms of every launch for nothing but skips.)
+    int64_t tile = (int64_t)blockIdx.x * 64;
+    unsigned long long todo = 0;
+    auto next_listed = [&]() -> int32_t {
+        for (;;) {
+            if (todo) {
+                const int b = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                return (int32_t)(tile - (int64_t)gridDim.x * 64) + b;
+            }
+            if (tile >= count) return count;
+            const int64_t i = tile + lane;
+            const bool in = i < count;
+            const int32_t pl = in ? (nodes ? nodes[i] : (int32_t)i) : 0;
+            const int fll = in ? (int)g.flags[pl] : 0;
+            const bool dirichlet = in && (fll & 1) && !(fll & 2);
+            if (dirichlet) {
+                const int32_t b0 = g.esup_ptr[pl], b1 = g.esup_ptr[pl + 1];
+                for (int32_t j = b0; j < b1; ++j) out[j] = 0.0;
+#ifdef NIN_BLOCK_STAMPS
+                if ((dbg >> 8) == 0) nws[pl] = 0.0;
+#else
+                nws[pl] = 0.0;
+#endif
+            }
+            todo = __ballot(in && !dirichlet);
+            tile += (int64_t)gridDim.x * 64;
+        }
+    };
     auto next_node = [&](int32_t idx) -> int32_t {
         group_sync<NW>();          // the node is done (its LDS may be reused) and the prefetched chunk index has landed
-        if (NW == 1) return idx + (int32_t)gridDim.x;
+        if (NW == 1) return next_listed();
         if (++within < CH) return idx + 1;
         within = 0;
         return ufirst(*slot) * CH;
@@ -430,7 +461,7 @@ __global__ __launch_bounds__(64 * NW) void nin_gls_block_kernel(GridView g, cons
         if (tid == 0) *slot = atomicAdd(queue, 1);
         group_sync<NW>();
     }
-    for (int32_t idx = NW == 1 ? (int32_t)blockIdx.x : ufirst(*slot) * CH; idx < count; idx = next_node(idx)) {
+    for (int32_t idx = NW == 1 ? next_listed() : ufirst(*slot) * CH; idx < count; idx = next_node(idx)) {
         if (NW > 1 && within == 0) {
             group_sync<NW>();      // every wave holds idx: the slot may be rewritten
             if (tid == 0) *slot = atomicAdd(queue, 1);
@@ -897,6 +928,7 @@ int launch_block(const GridView &g, const int32_t *nodes, int32_t count, int32_t
     if (per_cu < 1) per_cu = 1;
     int64_t blocks = (int64_t)256 * per_cu * 2;
     if (blocks > count) blocks = count;
+    if (NW == 1 && blocks > ((int64_t)count + 63) / 64) blocks = ((int64_t)count + 63) / 64;   // (a wave looks at 64 list entries per round)
     static const int max_blocks = getenv("NIN_GLS_BLOCK_MAX_BLOCKS") ? atoi(getenv("NIN_GLS_BLOCK_MAX_BLOCKS")) : 0;
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;   // diagnostic: occupancy experiments
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), (size_t)lds_bytes, stream, g, nodes, count, add_neumann,

@@ -413,12 +413,12 @@ __device__ __forceinline__ double strip_factor(double (&C)[NQ][NCB], int nc, int
     const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3, rowbase = 4 * sb + si;
     const double eye = si == sj ? 1.0 : 0.0;                     // the 4 x 4 identity in every quad
     const int n_panels = (nc + 3) >> 2;
-    static_assert(NQ >= 3 && NCB <= 12, "three generations of panels");
+    static_assert(NQ >= 3 && NCB >= 2 && NCB <= 12, "up to three generations of panels");
     for (int p = 0; p < (n_panels < 4 ? n_panels : 4); ++p) strip_panel<NQ, NCB, 0, NCB - 1>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
-    if constexpr (NCB > 5) {
+    if constexpr (NCB > 4) {
         for (int p = 4; p < (n_panels < 8 ? n_panels : 8); ++p) strip_panel<NQ, NCB, 1, NCB - 5>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
     }
-    if constexpr (NCB > 9) {
+    if constexpr (NCB > 8) {
         for (int p = 8; p < n_panels; ++p) strip_panel<NQ, NCB, 2, NCB - 9>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
     }
     // c sits in block 0, column nc & 3; r . r over the rows that never were pivot rows
@@ -434,7 +434,7 @@ __device__ __forceinline__ double strip_factor(double (&C)[NQ][NCB], int nc, int
 template <int FM, int DM, bool ROWS_IN_LANES, bool GENERAL, bool STRIPS = false>
 // (3 wavefronts per SIMD pay for the small instantiation -- wedge60 2.95 -> 2.72 ms, 160 B of spills; the large one spills
 //  inside its steps at 168 registers: 1.80 -> 2.32 ms)
-__global__ __launch_bounds__(256, (FM <= kMfwSmallFronts && !STRIPS ? 3 : 2)) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
+__global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_mfw_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                               const uint32_t *__restrict__ desc, int32_t count,
                                                               int add_neumann, double *__restrict__ out,
                                                               double *__restrict__ nws, int32_t *__restrict__ queue) {
@@ -943,6 +943,10 @@ int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc
                        count, add_neumann, out, nws, queue)
     if (kind == 2) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwWideDense, true, true, false);
     else if (kind == 1 && lane_columns) NIN_MFW_LAUNCH(kMfwSmallFronts, kMfwSmallDense, false, false, false);
+    // (the small instantiation keeps the row-lane form: with all 48 rows in ONE array a column costs it one product and one
+    //  update, and the strip form's fixed cost per reflector -- the same for 18 columns as for 36 -- eats what the matrix unit
+    //  saves: wedge60 2.66 ms either way, measured; NIN_MFW_SMALL_STRIPS=1 selects the strip form there)
+    else if (kind == 1 && getenv("NIN_MFW_SMALL_STRIPS") != nullptr) NIN_MFW_LAUNCH(kMfwSmallFronts, kMfwSmallDense, true, false, true);
     else if (kind == 1) NIN_MFW_LAUNCH(kMfwSmallFronts, kMfwSmallDense, true, false, false);
     else if (lane_columns) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, false, false, false);
     else if (no_strips) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, true, false, false);
