@@ -241,6 +241,34 @@ def test_gpu_multifrontal_first_form(oracle_lib, monkeypatch, kind):
     assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
 
 
+@pytest.mark.parametrize("kind,switch", [("tet", None), ("tet", "NIN_MFW_NO_STRIPS"), ("wedge", None), ("wedge", "NIN_MFW_SMALL_STRIPS"),
+                                         ("hex", "NIN_MFW_SMALL_STRIPS"), ("mixed", "NIN_MFW_NO_STRIPS")])
+def test_gpu_multifrontal_dense_phase_forms(oracle_lib, monkeypatch, kind, switch):
+    """The dense phase of the one-wavefront multifrontal kernel in each of its forms against the oracle: strips (16 x 4 tiles,
+    panels of four reflectors, trailing updates on the FP64 matrix unit: the default of the large instantiation), row lanes
+    (NIN_MFW_NO_STRIPS: round 2's form, the default of the small instantiation), strips in the small instantiation
+    (NIN_MFW_SMALL_STRIPS: wedge nodes 6 + 6 -- a partial last panel with c inside --, cube nodes 4 + 4 with the cube-node
+    kernel off -- c in a block of its own).  Nodes with fewer cells than the instantiation holds (mixed mesh: zero column
+    blocks, zero row tiles) ride along."""
+    if kind == "hex":
+        monkeypatch.setenv("NIN_GLS_NO_GROUP", "1")
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    mesh = {"tet": lambda: M.tet_mesh(6, jitter=0.1, seed=9), "wedge": lambda: M.wedge_mesh(6, 5, 4, jitter=0.06, seed=9),
+            "hex": lambda: M.hex_mesh(7, jitter=0.15, seed=9), "mixed": lambda: M.mixed_mesh(10, 5, 5, jitter=0.1, seed=9)}[kind]()
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(1, 0.0), seed=4)
+    o = oracle_lib.OracleInterpolator("port", threads=4)
+    o.load_mesh(mesh)
+    wo, no = o.prepare("gls", "u")
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+    plan = I.grid.gls_plan()
+    assert plan["mfw_large" if kind in ("tet", "mixed") else "mfw_small"] > 0
+    assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL
+    assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
+
+
 def test_gpu_multifrontal_general_kind(oracle_lib, monkeypatch):
     """Interior nodes whose cell graph has odd cycles (hex | pyramid and pyramid | tet interfaces: 16 and 26 cells) or
     cells with 4 faces at the node (pyramid apexes): the one-wavefront multifrontal kernel's general kind -- fronts = a
@@ -384,6 +412,8 @@ _GLS_ROUTES = {
     "default": (),                                                        # hex8mf / mfw (row lanes) / block for the rest
     "no_cube_kernel": ("NIN_GLS_NO_GROUP",),                              # cube nodes -> mfw small instantiation
     "mfw_lane_columns": ("NIN_GLS_NO_GROUP", "NIN_MFW_LANE_COLUMNS"),     # the mfw kernel's first form
+    "mfw_row_lanes": ("NIN_MFW_NO_STRIPS",),                              # its second form (round 2's default) where the strip form runs now
+    "mfw_small_strips": ("NIN_GLS_NO_GROUP", "NIN_MFW_SMALL_STRIPS"),     # the strip form in the small instantiation (wedge / cube nodes)
     "no_general_kind": ("NIN_GLS_NO_MFW_GENERAL",),                       # general-kind nodes -> block kernel
     "block_only": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"),                 # block kernel, 1 / 2 / 4 / 8 wavefronts per node
     "global_scratch": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_FORCE_GLOBAL"),   # the wave kernel
