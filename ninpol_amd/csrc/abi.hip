@@ -73,6 +73,7 @@ void dev_free_all(DeviceGrid &d) {
     if (d.ev_weights) (void)hipEventDestroy(static_cast<hipEvent_t>(d.ev_weights));
     if (d.ev_scan) (void)hipEventDestroy(static_cast<hipEvent_t>(d.ev_scan));
     if (d.copy_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(d.copy_stream));
+    if (d.copy_stream2) (void)hipStreamDestroy(static_cast<hipStream_t>(d.copy_stream2));
     for (void *p : d.allocs) (void)hipFree(p);
     d.allocs.clear();
     d = DeviceGrid{};
@@ -424,9 +425,23 @@ int nin_grid_to_device(nin_grid *g, int device) {
         d.gls_scratch_stride = need_max[kGlsClasses - 1] / 8;
         if ((rc = dev_alloc(d, &d.gls_scratch, (size_t)d.gls_scratch_slots * d.gls_scratch_stride))) return rc;
     }
+    // interpolate()'s pipeline: chunk boundaries (multiples of 64 nodes) and where they fall in every (ascending) list
+    {
+        constexpr int K = DeviceGrid::kE2eChunks;
+        for (int k = 0; k <= K; ++k) d.chunk_node[k] = k == K ? (int32_t)P : (int32_t)((P * k / K) & ~(int64_t)63);
+        auto cut = [&](int li, const std::vector<int32_t> &v) {
+            for (int k = 0; k <= K; ++k)
+                d.chunk_off[li][k] = (int32_t)(std::lower_bound(v.begin(), v.end(), d.chunk_node[k]) - v.begin());
+        };
+        for (int c = 0; c < kGlsClasses; ++c) cut(c, lists[c]);
+        cut(kGlsClasses, hex8_list);
+        for (int i = 0; i < 3; ++i) cut(kGlsClasses + 1 + i, mfw_list[i]);
+        const char *mn = getenv("NIN_E2E_MIN_NODES");                                // (tests: the pipeline on small meshes too)
+        d.chunkable = P >= (mn ? atoll(mn) : 64 * 1024) && P >= 64 * K && getenv("NIN_E2E_NO_PIPELINE") == nullptr;   // small meshes: one piece
+    }
     // a single class holding every node in order needs no list: the kernel walks 0..P-1 directly
     for (int c = 0; c < kGlsClasses; ++c)
-        if (d.gls[c].count == P) d.gls[c].nodes = nullptr;
+        if (d.gls[c].count == P) { d.gls[c].nodes = nullptr; d.chunkable = false; }
     HIP_TRY(hipDeviceSynchronize());
     return NIN_OK;
 }
@@ -686,6 +701,109 @@ int csr_compact_pipelined(nin_grid *g, const double *dev_csr_data, const double 
 
 }  // namespace
 
+namespace {
+
+// The weight kernels for the nodes of chunk k only (all nodes of the chunk, add_neumann fused): sub-ranges of the launch plan's lists.
+int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipStream_t stream) {
+    DeviceGrid &d = g->d;
+    const int32_t P = (int32_t)g->h.n_points;
+    if (method != NIN_METHOD_GLS)
+        return launch_rows_range(d.v, method == NIN_METHOD_LS ? 1 : 0, P, d.chunk_node[k], d.chunk_node[k + 1],
+                                 (int32_t)g->h.mx_elems_per_point, out, nws, stream);
+    HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
+    int rc = 0;
+    {
+        const int32_t b = d.chunk_off[kGlsClasses][k], n = d.chunk_off[kGlsClasses][k + 1] - b;
+        if (n > 0) rc = launch_gls_hex8mf(d.v, d.hex8.nodes + b, d.hex8_desc + 4 * (size_t)b, n, 1, out, nws, d.gls_queue, stream);
+    }
+    for (int i = 0; i < 3 && !rc; ++i) {
+        const int32_t b = d.chunk_off[kGlsClasses + 1 + i][k], n = d.chunk_off[kGlsClasses + 1 + i][k + 1] - b;
+        if (n > 0) rc = launch_gls_mfw(d.v, d.mfw[i].nodes + b, d.mfw_desc[i] + (size_t)kMfwDescWords * b, n, i, 1, out, nws,
+                                       d.gls_queue + 5 + i, stream);
+    }
+    for (int c = 0; c < kGlsClasses && !rc; ++c) {
+        const int32_t b = d.chunk_off[c][k], n = d.chunk_off[c][k + 1] - b;
+        if (n <= 0) continue;
+        const auto &kc = d.gls[c];
+        if (c < kGlsClasses - 1)
+            rc = launch_gls_block(d.v, kc.nodes + b, n, kc.waves, kc.col_slots, kc.lds_bytes, 1, out, nws, d.gls_queue + 1 + c, stream);
+        else
+            rc = launch_gls_class(d.v, kc.nodes + b, n, 0, kc.rows_per_lane, 1, out, nws, d.gls_scratch, d.gls_scratch_stride,
+                                  d.gls_scratch_slots, stream);
+    }
+    return rc ? fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError())) : NIN_OK;
+}
+
+// interpolate() as a pipeline over kE2eChunks pieces of the node range: while piece k's surviving entries cross PCIe (the floor
+// of this path: 0.95 GB at 57 GB/s = 16.7 ms at 10 M cells), piece k + 1 is computed, counted, scanned and compacted.  Per piece:
+// weight kernels -> non-zeros per row -> exclusive scan seeded with the entries of the pieces before -> (4 bytes back: the
+// running total) -> compaction -> its slices of indptr / indices / data leave on the copy queues.
+int interpolate_chunked(nin_grid *g, int method, int32_t *indptr, int32_t *indices, double *data, int64_t *nnz_out,
+                        double *neumann_ws) {
+    DeviceGrid &d = g->d;
+    constexpr int K = DeviceGrid::kE2eChunks;
+    const int64_t P = g->h.n_points;
+    Laps L;
+    int rc = NIN_OK;
+    if ((rc = e2e_streams(d))) return rc;
+    hipStream_t cs = static_cast<hipStream_t>(d.copy_stream), stream = nullptr;
+    hipEvent_t ev = static_cast<hipEvent_t>(d.ev_scan);
+#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+    if (!d.e2e_cnt && (rc = dev_alloc(d, &d.e2e_cnt, (size_t)(P + 1)))) return rc;
+    if (!d.e2e_ptr && (rc = dev_alloc(d, &d.e2e_ptr, (size_t)(P + 1)))) return rc;
+    const size_t cap = (size_t)std::max<int64_t>(d.nnz_e, 1);
+    if (!d.e2e_indices && (rc = dev_alloc(d, &d.e2e_indices, cap))) return rc;
+    if (!d.e2e_data && (rc = dev_alloc(d, &d.e2e_data, cap))) return rc;
+    size_t tmp_bytes = 0;
+    TRY_C(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_bytes, d.e2e_cnt, d.e2e_ptr, hipcub::Sum(), (int32_t)0, (int)(P + 1), stream));
+    if (tmp_bytes > d.e2e_tmp_bytes) {
+        char *t = nullptr;
+        if ((rc = dev_alloc(d, &t, std::max<size_t>(tmp_bytes, 16)))) return rc;
+        d.e2e_tmp = t;
+        d.e2e_tmp_bytes = tmp_bytes;
+    }
+    TRY_C(hipMemsetAsync(d.e2e_cnt, 0, (size_t)(P + 1) * 4, stream));
+    int32_t base = 0;
+    for (int k = 0; k < K; ++k) {
+        const int32_t pb = d.chunk_node[k], pe = d.chunk_node[k + 1];
+        if (pe <= pb) continue;
+        if ((rc = weights_chunk(g, method, k, d.e2e_weights, d.e2e_nws, stream))) return rc;
+        if ((rc = launch_row_nnz(d.v, d.e2e_weights, d.e2e_cnt, stream, pb, pe))) return fail(rc, "launch failed");
+        size_t tb = d.e2e_tmp_bytes;
+        // ptr[pb .. pe] (one past the piece: the next piece's seed and, in the end, nnz); cnt[pe] is not part of that sum
+        TRY_C(hipcub::DeviceScan::ExclusiveScan(d.e2e_tmp, tb, d.e2e_cnt + pb, d.e2e_ptr + pb, hipcub::Sum(), base, (int)(pe - pb + 1), stream));
+        if ((rc = launch_compact(d.v, d.e2e_weights, d.e2e_ptr, d.e2e_indices, d.e2e_data, stream, pb, pe))) return fail(rc, "launch failed");
+        int32_t next_base = 0;
+        TRY_C(hipMemcpyAsync(&next_base, d.e2e_ptr + pe, 4, hipMemcpyDeviceToHost, stream));
+        TRY_C(hipEventRecord(ev, stream));
+        TRY_C(hipStreamSynchronize(stream));             // (the piece is compacted; the copies of the piece before still run)
+        const int64_t n_k = (int64_t)next_base - base;
+        // this piece's slices: rows on the copy stream, entries split over two queues
+        TRY_C(hipMemcpyAsync(indptr + pb, d.e2e_ptr + pb, (size_t)(pe - pb + (k == K - 1 ? 1 : 0)) * 4, hipMemcpyDeviceToHost, cs));
+        TRY_C(hipMemcpyAsync(neumann_ws + pb, d.e2e_nws + pb, (size_t)(pe - pb) * 8, hipMemcpyDeviceToHost, cs));
+        if (n_k > 0) {
+            TRY_C(hipMemcpyAsync(data + base, d.e2e_data + base, (size_t)n_k * 8, hipMemcpyDeviceToHost, cs));
+            if (!d.copy_stream2) {
+                hipStream_t s2;
+                TRY_C(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+                d.copy_stream2 = s2;
+            }
+            TRY_C(hipMemcpyAsync(indices + base, d.e2e_indices + base, (size_t)n_k * 4, hipMemcpyDeviceToHost,
+                                 static_cast<hipStream_t>(d.copy_stream2)));
+        }
+        base = next_base;
+        if (L.on) { char nm[32]; snprintf(nm, sizeof nm, "piece %d computed", k); L.lap(nm); }
+    }
+    TRY_C(hipStreamSynchronize(cs));
+    if (d.copy_stream2) TRY_C(hipStreamSynchronize(static_cast<hipStream_t>(d.copy_stream2)));
+    L.lap("copies drained");
+    *nnz_out = base;
+#undef TRY_C
+    return NIN_OK;
+}
+
+}  // namespace
+
 int nin_csr_compact_host(nin_grid *g, const double *dev_csr_data, int32_t *indptr, int32_t *indices, double *data,
                          int64_t *nnz_out, void *stream_) {
     if (!g || !dev_csr_data || !indptr || !nnz_out) return fail(NIN_EINVAL, "NULL argument");
@@ -705,6 +823,14 @@ int nin_interpolate_csr_host(nin_grid *g, int method, int32_t *indptr, int32_t *
     int rc = NIN_OK;
     if (!d.e2e_weights && (rc = dev_alloc(d, &d.e2e_weights, (size_t)std::max<int64_t>(d.nnz_e, 1)))) return rc;
     if (!d.e2e_nws && (rc = dev_alloc(d, &d.e2e_nws, (size_t)std::max<int64_t>(g->h.n_points, 1)))) return rc;
+    if (d.chunkable) {
+        if (!d.fields_set) return fail(NIN_ESTATE, "nin_fields_set has not been called");
+        if (method != NIN_METHOD_GLS && method != NIN_METHOD_IDW && method != NIN_METHOD_LS) return fail(NIN_EINVAL, "unknown method %d", method);
+        if (method == NIN_METHOD_GLS && !d.have_perm) return fail(NIN_ESTATE, "GLS needs permeability and diff_mag");
+        if (method == NIN_METHOD_GLS && d.gls_too_large)
+            return fail(NIN_ERANGE, "a node's GLS system has more than 1024 rows (more than ~100 cells around one node): beyond the fallback kernel");
+        return interpolate_chunked(g, method, indptr, indices, data, nnz_out, neumann_ws);
+    }
     rc = nin_weights_device(g, method, nullptr, 0, 1, d.e2e_weights, d.e2e_nws, nullptr);
     if (!rc) rc = csr_compact_pipelined(g, d.e2e_weights, d.e2e_nws, indptr, indices, data, nnz_out, neumann_ws, nullptr);
     return rc;

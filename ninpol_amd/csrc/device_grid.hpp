@@ -95,8 +95,15 @@ struct DeviceGrid {
     size_t e2e_tmp_bytes = 0;
     double *apply_weights = nullptr;   // [nnz_e] weights of the last nin_apply_device (allocated on first use)
     uint8_t *flag_staging = nullptr;   // page-locked [n_points]: nin_fields_set packs the node flags here and uploads from it
-    void *copy_stream = nullptr;       // hipStream_t of the device-to-host copies that run under the compaction kernels
+    void *copy_stream = nullptr, *copy_stream2 = nullptr;   // hipStream_t of the device-to-host copies that run under the kernels
     void *ev_weights = nullptr, *ev_scan = nullptr;   // hipEvent_t: weights written / row pointers scanned
+    // interpolate()'s pipeline (abi.hip, interpolate_chunked): the node range is cut into kE2eChunks pieces at multiples of 64 nodes;
+    // every GLS list is ascending, so a piece is a sub-range of each: chunk_off[list][k] .. chunk_off[list][k + 1]
+    // (lists 0 .. kGlsClasses - 1: the block kernel's classes, then the cube-node kernel, then the three mfw kinds)
+    static constexpr int kE2eChunks = 4;
+    int32_t chunk_node[kE2eChunks + 1] = {0, 0, 0, 0, 0};
+    int32_t chunk_off[kGlsClasses + 4][kE2eChunks + 1] = {};
+    bool chunkable = false;
     bool gls_too_large = false;     // some node's system has more rows than the scratch kernel handles (1024)
 };
 

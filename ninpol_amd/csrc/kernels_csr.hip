@@ -16,8 +16,8 @@ namespace nin {
 namespace {
 
 __global__ __launch_bounds__(256) void nin_row_nnz_kernel(GridView g, const double *__restrict__ data,
-                                                          int32_t *__restrict__ row_nnz) {
-    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < g.n_points; p += gridDim.x * blockDim.x) {
+                                                          int32_t *__restrict__ row_nnz, int32_t p_begin, int32_t p_end) {
+    for (int32_t p = p_begin + blockIdx.x * blockDim.x + threadIdx.x; p < p_end; p += gridDim.x * blockDim.x) {
         int32_t c = 0;
         for (int32_t q = g.esup_ptr[p]; q < g.esup_ptr[p + 1]; ++q) c += (data[q] != 0.0);
         row_nnz[p] = c;
@@ -30,10 +30,11 @@ __global__ __launch_bounds__(256) void nin_row_nnz_kernel(GridView g, const doub
 // rocprofv3 WRITE_SIZE 4.97 GB for 0.95 GB of output, 2.34 ms at 10 M cells (profiles/r03, before) -- now ~0.5 ms.
 __global__ __launch_bounds__(256) void nin_compact_kernel(GridView g, const double *__restrict__ data,
                                                           const int32_t *__restrict__ new_ptr,
-                                                          int32_t *__restrict__ indices, double *__restrict__ vals) {
+                                                          int32_t *__restrict__ indices, double *__restrict__ vals,
+                                                          int32_t tile_begin, int32_t tile_end) {
     const int lane = threadIdx.x & 63;
-    const int32_t n_tiles = (g.n_points + 63) / 64, wpb = blockDim.x >> 6;
-    for (int32_t tile = blockIdx.x * wpb + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * wpb) {
+    const int32_t wpb = blockDim.x >> 6;
+    for (int32_t tile = tile_begin + blockIdx.x * wpb + (threadIdx.x >> 6); tile < tile_end; tile += gridDim.x * wpb) {
         const int32_t p0 = tile * 64, pe = p0 + 64 < g.n_points ? p0 + 64 : g.n_points;
         const int32_t run_b = g.esup_ptr[p0], run_e = g.esup_ptr[pe];
         int32_t at = new_ptr[p0];
@@ -112,14 +113,20 @@ int grid_for(int64_t n) {
 
 }  // namespace
 
-int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipStream_t stream) {
-    hipLaunchKernelGGL(nin_row_nnz_kernel, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, row_nnz);
+// rows [p_begin, p_end) (p_end < 0: all; p_begin a multiple of 64)
+int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipStream_t stream, int32_t p_begin, int32_t p_end) {
+    if (p_end < 0) p_end = g.n_points;
+    if (p_end <= p_begin) return 0;
+    hipLaunchKernelGGL(nin_row_nnz_kernel, dim3(grid_for(p_end - p_begin)), dim3(256), 0, stream, g, data, row_nnz, p_begin, p_end);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr, int32_t *indices,
-                   double *vals, hipStream_t stream) {
-    hipLaunchKernelGGL(nin_compact_kernel, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, new_ptr, indices, vals);
+                   double *vals, hipStream_t stream, int32_t p_begin, int32_t p_end) {
+    if (p_end < 0) p_end = g.n_points;
+    if (p_end <= p_begin) return 0;
+    hipLaunchKernelGGL(nin_compact_kernel, dim3(grid_for(p_end - p_begin)), dim3(256), 0, stream, g, data, new_ptr, indices, vals,
+                       p_begin / 64, (int32_t)(((int64_t)p_end + 63) / 64));
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -149,13 +149,14 @@ __device__ __forceinline__ void ls_row(const GridView &g, int32_t p, const int32
 // cap = entries of LDS each wave owns; a 64-node run longer than that is handled straight from HBM.
 template <int METHOD>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void nin_rows_kernel(GridView g, int32_t n, int32_t cap,
-                                                                      double *__restrict__ out, double *__restrict__ nws) {
+                                                                      double *__restrict__ out, double *__restrict__ nws,
+                                                                      int32_t tile_begin, int32_t tile_end) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *wbuf = smem + (size_t)wave * cap + (size_t)wave * ((cap + 1) >> 1);   // [cap] weights
     int32_t *cbuf = reinterpret_cast<int32_t *>(wbuf + cap);                        // [cap] cell ids
-    const int32_t n_tiles = (n + 63) / 64;
-    for (int32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
+    // tiles [tile_begin, tile_end) of 64 nodes (all of them, or one chunk of the pipelined interpolate())
+    for (int32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave; tile < tile_end; tile += gridDim.x * kWavesPerBlock) {
         const int32_t p0 = tile * 64, p = p0 + lane;
         const int32_t pe = p0 + 64 < n ? p0 + 64 : n;
         const int32_t run_b = g.esup_ptr[p0], run_e = g.esup_ptr[pe];   // wave-uniform loads
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void nin_rows_targets_kernel(GridView g, const
 
 template <int METHOD>
 int launch_rows(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, double *out, double *nws,
-                hipStream_t stream) {
+                hipStream_t stream, int32_t p_begin = 0, int32_t p_end = -1) {
     if (n_targets <= 0) return 0;
     if (targets) {
         int64_t blocks = ((int64_t)n_targets + 255) / 256;
@@ -236,12 +237,15 @@ int launch_rows(const GridView &g, const int32_t *targets, int32_t n_targets, in
     if (cap > 1024) cap = 1024;
     cap = (cap + 1) & ~(int64_t)1;
     const size_t dyn = (size_t)kWavesPerBlock * (cap * 8 + ((cap + 1) / 2) * 8);
-    const int64_t tiles = ((int64_t)n_targets + 63) / 64;
+    if (p_end < 0 || p_end > n_targets) p_end = n_targets;
+    const int32_t tile_begin = p_begin / 64, tile_end = (int32_t)(((int64_t)p_end + 63) / 64);   // (p_begin: a multiple of 64)
+    const int64_t tiles = tile_end - tile_begin;
+    if (tiles <= 0) return 0;
     int64_t blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t cap_blocks = 256 * 8;
     if (blocks > cap_blocks) blocks = cap_blocks;
     hipLaunchKernelGGL((nin_rows_kernel<METHOD>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), dyn, stream, g, n_targets,
-                       (int32_t)cap, out, nws);
+                       (int32_t)cap, out, nws, tile_begin, tile_end);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -255,6 +259,12 @@ int launch_idw(const GridView &g, const int32_t *targets, int32_t n_targets, int
 int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, double *out, double *nws,
               hipStream_t stream) {
     return launch_rows<1>(g, targets, n_targets, mx_row, out, nws, stream);
+}
+
+int launch_rows_range(const GridView &g, int method_ls, int32_t n_points, int32_t p_begin, int32_t p_end, int32_t mx_row,
+                      double *out, double *nws, hipStream_t stream) {
+    return method_ls ? launch_rows<1>(g, nullptr, n_points, mx_row, out, nws, stream, p_begin, p_end)
+                     : launch_rows<0>(g, nullptr, n_points, mx_row, out, nws, stream, p_begin, p_end);
 }
 
 }  // namespace nin

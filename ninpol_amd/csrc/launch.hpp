@@ -41,9 +41,13 @@ const char *kernel_name_gls_mfw();
 // out[j] += nws[row(j)] for IDW / LS is a no-op (their neumann_ws is 0): nothing to launch.
 
 // CSR finish (interpolator.pyx:622-624): count non-zeros per row, scan, compact
-int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipStream_t stream);
+// rows [p_begin, p_end) only (p_end < 0: to the last node; p_begin: a multiple of 64)
+int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipStream_t stream, int32_t p_begin = 0, int32_t p_end = -1);
 int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr, int32_t *indices,
-                   double *vals, hipStream_t stream);
+                   double *vals, hipStream_t stream, int32_t p_begin = 0, int32_t p_end = -1);
+// IDW (method_ls = 0) / LS (1) weights of the nodes [p_begin, p_end) (p_begin: a multiple of 64)
+int launch_rows_range(const GridView &g, int method_ls, int32_t n_points, int32_t p_begin, int32_t p_end, int32_t mx_row,
+                      double *out, double *nws, hipStream_t stream);
 
 int launch_apply(const GridView &g, const double *data, const double *u, double *values, hipStream_t stream);
 // k fields at once: u [k][n_elems], values [k][n_points]

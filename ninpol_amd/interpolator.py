@@ -77,10 +77,35 @@ def _table_key(a):
     return (a.__array_interface__["data"][0], a.size, h.value)
 
 
-def _upload_fields(grid, method, cells_data, points_data, variable_to_index, variable, device=0, always_perm=False):
+class _TableCheck:
+    """Is the permeability / diff_mag resident on the device still the caller's?  The answer is a hash of all 0.8 GB of the
+    two tables (10 M cells: 3-5 ms on the host's OpenMP team); it is computed on a thread WHILE the kernels already run with the
+    resident copy -- ctypes releases the GIL for both -- and only a caller who really edited a table pays a second run."""
+
+    def __init__(self, grid, perm, dmag):
+        import threading
+        self.grid, self.perm, self.dmag, self.key = grid, perm, dmag, None
+        self._t = threading.Thread(target=self._hash)
+        self._t.start()
+
+    def _hash(self):
+        self.key = (_table_key(self.perm), _table_key(self.dmag))
+
+    def stale(self):
+        self._t.join()
+        return self.key != self.grid._perm_key
+
+    def upload(self, flag):
+        _lib.check(_lib.load().nin_fields_set(self.grid._h, _ptr(self.perm), _ptr(self.dmag), _ptr(flag), None))
+        self.grid._perm_key = self.key
+
+
+def _upload_fields(grid, method, cells_data, points_data, variable_to_index, variable, device=0, always_perm=False,
+                   speculate=False):
     """Look the field rows up exactly as the plugins do (idw.pyx:27, ls.pyx:27, gls.pyx:47-59; a missing
     name is a KeyError there too) and hand them to the device.  always_perm: upload permeability / diff_mag whenever
-    the mesh has them (a DevicePlan serves any method afterwards)."""
+    the mesh has them (a DevicePlan serves any method afterwards).  speculate: when a permeability is resident already,
+    upload the flags only and return a _TableCheck (the caller launches at once and asks it afterwards); else None."""
     L = _lib.load()
     if grid.device < 0:   # the GPU its Interpolator was built for (a bare Grid handed to a plugin: device 0)
         grid.to_device(getattr(grid, "preferred_device", device))
@@ -89,21 +114,29 @@ def _upload_fields(grid, method, cells_data, points_data, variable_to_index, var
     flag = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_flag_" + variable]][:P], dtype=DTYPE_F)
     perm = dmag = nval = None
     key = None
+    check = None
     if method == "gls" or (always_perm and "permeability" in v2i["cells"]):
         cd = np.asarray(cells_data)
         perm = np.ascontiguousarray(cd[v2i["cells"]["permeability"]][:E * 9], dtype=DTYPE_F)
         dmag = np.ascontiguousarray(cd[v2i["cells"]["diff_mag"]][:E], dtype=DTYPE_F)
         if method == "gls":
             nval = np.ascontiguousarray(np.asarray(points_data)[v2i["points"]["neumann_" + variable]][:P], dtype=DTYPE_F)
-        # permeability and diff_mag belong to the mesh: 0.8 GB at 10 M cells, uploaded once per table contents
-        key = (_table_key(perm), _table_key(dmag))
-        if getattr(grid, "_perm_key", None) == key and grid.device >= 0:
+        if speculate and getattr(grid, "_perm_key", None) is not None:
+            check = _TableCheck(grid, perm, dmag)
             perm = dmag = None
+        else:
+            # permeability and diff_mag belong to the mesh: 0.8 GB at 10 M cells, uploaded once per table contents
+            key = (_table_key(perm), _table_key(dmag))
+            if getattr(grid, "_perm_key", None) == key and grid.device >= 0:
+                perm = dmag = None
     _lib.check(L.nin_fields_set(grid._h, _ptr(perm), _ptr(dmag), _ptr(flag), _ptr(nval)))
     if key is not None:
         grid._perm_key = key
     # the flags on the device belong to the GRID, not to a plan: remember whose they are (DevicePlan.ensure_current)
     grid._fields_variable = variable
+    if check is not None:
+        check.flag = flag
+    return check
 
 
 def _run_weights(grid, method, cells_data, points_data, variable_to_index, variable, target_points, add_neumann):
@@ -380,8 +413,12 @@ class Interpolator:
         if full and idx_t is np.int32:
             # one native call: kernel with `data[j] = weights + neumann_ws[row]` (interpolator.pyx:618) fused, then the
             # device-side csr_matrix + eliminate_zeros (interpolator.pyx:622-624); only the surviving entries cross PCIe
-            _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable)
+            check = _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable, speculate=True)
             indptr, indices, data, nws = _native_interpolate(g, method)
+            if check is not None and check.stale():      # the caller's permeability is not the resident one: again, with it
+                del indptr, indices, data, nws
+                check.upload(check.flag)
+                indptr, indices, data, nws = _native_interpolate(g, method)
             self._log(f"Interpolation done in {time.time() - t0:.2f} seconds")
             return _wrap_csr(data, indices, indptr, (P, E)), nws
         csr, nws = _run_weights(g, method, self.cells_data, self.points_data, self.variable_to_index, variable,

@@ -605,3 +605,32 @@ def test_gpu_csr_result_is_canonical_and_scratch_can_be_released():
         I.release_scratch(pinned=False)
         vals2, _ = I.apply("u", meth)
         assert np.array_equal(vals, vals2, equal_nan=True)
+
+
+@pytest.mark.parametrize("kind", ["hex", "mixed", "tet"])
+def test_gpu_interpolate_pipeline_equals_one_piece(monkeypatch, kind):
+    """interpolate() in pieces (weights, count, seeded scan, compaction and PCIe slices per quarter of the node range -- the
+    default from 64 k nodes on) against interpolate() in one piece: identical CSR and neumann_ws, every method, with Neumann
+    nodes and rows that vanish; and the chunk boundaries really cut every GLS list (all kernels run in every piece)."""
+    mesh = {"hex": lambda: M.hex_mesh(13, 11, 9, jitter=0.15, seed=2), "mixed": lambda: M.mixed_mesh(12, 6, 6, jitter=0.1, seed=2),
+            "tet": lambda: M.tet_mesh(7, jitter=0.1, seed=2)}[kind]()
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=3)
+    res = {}
+    for mode in ("one", "pieces"):
+        with monkeypatch.context() as mp:
+            if mode == "one":
+                mp.setenv("NIN_E2E_NO_PIPELINE", "1")
+            else:
+                mp.setenv("NIN_E2E_MIN_NODES", "0")
+            I = _interp()
+            I.load_mesh(mesh_obj=mesh)
+            assert I.grid.n_points >= 256
+            for meth in ("gls", "idw", "ls"):
+                W, nws = I.interpolate("u", meth)
+                W2, nws2 = I.interpolate("u", meth)          # buffers of the path are reused
+                assert np.array_equal(W.data, W2.data, equal_nan=True)
+                res[(mode, meth)] = (W.indptr.copy(), W.indices.copy(), W.data.copy(), np.array(nws))
+    for meth in ("gls", "idw", "ls"):
+        a, b = res[("one", meth)], res[("pieces", meth)]
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True), meth
