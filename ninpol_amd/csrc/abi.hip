@@ -748,7 +748,13 @@ int interpolate_chunked(nin_grid *g, int method, int32_t *indptr, int32_t *indic
     if ((rc = e2e_streams(d))) return rc;
     hipStream_t cs = static_cast<hipStream_t>(d.copy_stream), stream = nullptr;
     hipEvent_t ev = static_cast<hipEvent_t>(d.ev_scan);
-#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+    // an error in the middle must not leave copies into the caller's buffers in flight
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(cs);
+        if (d.copy_stream2) (void)hipStreamSynchronize(static_cast<hipStream_t>(d.copy_stream2));
+        (void)hipStreamSynchronize(stream);
+    };
+#define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { drain(); return fail(NIN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
     if (!d.e2e_cnt && (rc = dev_alloc(d, &d.e2e_cnt, (size_t)(P + 1)))) return rc;
     if (!d.e2e_ptr && (rc = dev_alloc(d, &d.e2e_ptr, (size_t)(P + 1)))) return rc;
     const size_t cap = (size_t)std::max<int64_t>(d.nnz_e, 1);
@@ -767,12 +773,12 @@ int interpolate_chunked(nin_grid *g, int method, int32_t *indptr, int32_t *indic
     for (int k = 0; k < K; ++k) {
         const int32_t pb = d.chunk_node[k], pe = d.chunk_node[k + 1];
         if (pe <= pb) continue;
-        if ((rc = weights_chunk(g, method, k, d.e2e_weights, d.e2e_nws, stream))) return rc;
-        if ((rc = launch_row_nnz(d.v, d.e2e_weights, d.e2e_cnt, stream, pb, pe))) return fail(rc, "launch failed");
+        if ((rc = weights_chunk(g, method, k, d.e2e_weights, d.e2e_nws, stream))) { drain(); return rc; }
+        if ((rc = launch_row_nnz(d.v, d.e2e_weights, d.e2e_cnt, stream, pb, pe))) { drain(); return fail(rc, "launch failed"); }
         size_t tb = d.e2e_tmp_bytes;
         // ptr[pb .. pe] (one past the piece: the next piece's seed and, in the end, nnz); cnt[pe] is not part of that sum
         TRY_C(hipcub::DeviceScan::ExclusiveScan(d.e2e_tmp, tb, d.e2e_cnt + pb, d.e2e_ptr + pb, hipcub::Sum(), base, (int)(pe - pb + 1), stream));
-        if ((rc = launch_compact(d.v, d.e2e_weights, d.e2e_ptr, d.e2e_indices, d.e2e_data, stream, pb, pe))) return fail(rc, "launch failed");
+        if ((rc = launch_compact(d.v, d.e2e_weights, d.e2e_ptr, d.e2e_indices, d.e2e_data, stream, pb, pe))) { drain(); return fail(rc, "launch failed"); }
         int32_t next_base = 0;
         TRY_C(hipMemcpyAsync(&next_base, d.e2e_ptr + pe, 4, hipMemcpyDeviceToHost, stream));
         TRY_C(hipEventRecord(ev, stream));

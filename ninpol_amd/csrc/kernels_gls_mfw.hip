@@ -282,11 +282,12 @@ __device__ __forceinline__ void sum_rows2(double &a, double &b) {
 
 // One panel step K on the panel's tiles P[q], q >= Q0 (column block 0): pivot row rp = 4 p + K = (tile Q0, quad bp, i = K).
 // Tiles above Q0 hold rows below every pivot of this panel: no masks there.  vp[K], gk[K]: the reflector's pivot entry and scalar.
-// Tc[i] (i < K): on exit T[i][K] of the panel's triangular factor, T[0:K, K] = -g_K T[0:K, 0:K] (V^T v_K): the products
-// v_i . v_K (i < K) are the SAME sums as the step's own dots -- column i below the pivot still holds v_i -- so they come out of
-// the step's one reduction, in the lanes j = i.
+// Tr[K]: on exit this lane's entry T[si][K] of the panel's triangular factor (H_0 .. H_3 = I - V T V^T: T[K][K] = g_K,
+// T[0:K, K] = -g_K T[0:K, 0:K] (V^T v_K)).  The products v_l . v_K (l < K) are the SAME sums as the step's own dots -- column
+// l below the pivot still holds v_l -- so they come out of the step's one reduction, in the lanes j = l; and since row si of T
+// is zero left of its diagonal, sum_l Tr[l] G[l][K] over ALL l < K is the right sum in every lane (zero below the diagonal).
 template <int NQ, int Q0, int K>
-__device__ __forceinline__ void strip_panel_step(double (&P)[NQ], double (&vp)[4], double (&gk)[4], double (&T)[4][4], int bp, int si, int sb, int sj) {
+__device__ __forceinline__ void strip_panel_step(double (&P)[NQ], double (&vp)[4], double (&gk)[4], double (&Tr)[4], int bp, int si, int sb, int sj) {
     const bool in_piv_quad = sb == bp;
     const bool is_piv = in_piv_quad && si == K;                  // this lane's row of tile Q0 is the pivot row
     const bool below0 = sb > bp || (in_piv_quad && si > K);      // ... lies below it
@@ -297,26 +298,20 @@ __device__ __forceinline__ void strip_panel_step(double (&P)[NQ], double (&vp)[4
         xm[q] = (q == Q0 && !below0) ? 0.0 : xk;                 // the reflector's entries below the pivot
         acc = fma(xm[q], P[q], acc);                             // lane (.., j): sum over its rows of a[r][K] a[r][j]
     }
-    double d = sum_quads(acc), ap = sum_quads(is_piv ? P[Q0] : 0.0);   // (the pivot row's entry of column j, from its quad)
-    sum_rows2(d, ap);
+    // the pivot row's entry of column j, for every lane with that j: a shuffle from lane (K, bp, j) -- its latency hides behind the reduction
+    const double ap = __shfl(P[Q0], 16 * K + 4 * bp + sj);
+    const double d = sum_rows(sum_quads(acc));
     const House h = house_unguarded(quad_pick<K>(ap), quad_pick<K>(d));
     const double e = fma(h.vp, ap, d);                           // v_K . (column j): j > K the columns still to update, j < K v_j
     const double w = sj > K ? -(h.g * e) : 0.0;                  // w_j = -g (v . a_j), the panel's later columns only
     gk[K] = h.g;
     vp[K] = h.vp;
-    T[K][K] = h.g;
-    if (K >= 1) {
-        double Gk[3];
-        Gk[0] = quad_pick<0>(e);
-        if (K >= 2) Gk[1] = quad_pick<1>(e);
-        if (K >= 3) Gk[2] = quad_pick<2>(e);
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            double t = T[i][i] * Gk[i];
-#pragma unroll
-            for (int l = i + 1; l < K; ++l) t = fma(T[i][l], Gk[l], t);
-            T[i][K] = -(h.g * t);
-        }
+    {
+        double t = 0.0;
+        if (K >= 1) t = Tr[0] * quad_pick<0>(e);
+        if (K >= 2) t = fma(Tr[1], quad_pick<1>(e), t);
+        if (K >= 3) t = fma(Tr[2], quad_pick<2>(e), t);
+        Tr[K] = si == K ? h.g : -(h.g * t);
     }
 #pragma unroll
     for (int q = Q0; q < NQ; ++q) {
@@ -331,15 +326,15 @@ template <int NQ, int NCB, int Q0, int NT>
 __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc, int si, int sb, int sj, double eye, double *Rm, int RP, SubStamps &ST) {
     const int bp = p & 3, steps = nc - 4 * p < 4 ? nc - 4 * p : 4;
     double V[NQ], gk[4] = {0.0, 0.0, 0.0, 0.0}, vp[4] = {0.0, 0.0, 0.0, 0.0};
-    double T[4][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    double Tr[4] = {0.0, 0.0, 0.0, 0.0};   // this lane's row si of T (a step that did not run leaves its column zero)
     {
         double P[NQ];
 #pragma unroll
         for (int q = Q0; q < NQ; ++q) P[q] = C[q][0];
-        strip_panel_step<NQ, Q0, 0>(P, vp, gk, T, bp, si, sb, sj);
-        if (steps > 1) strip_panel_step<NQ, Q0, 1>(P, vp, gk, T, bp, si, sb, sj);
-        if (steps > 2) strip_panel_step<NQ, Q0, 2>(P, vp, gk, T, bp, si, sb, sj);
-        if (steps > 3) strip_panel_step<NQ, Q0, 3>(P, vp, gk, T, bp, si, sb, sj);
+        strip_panel_step<NQ, Q0, 0>(P, vp, gk, Tr, bp, si, sb, sj);
+        if (steps > 1) strip_panel_step<NQ, Q0, 1>(P, vp, gk, Tr, bp, si, sb, sj);
+        if (steps > 2) strip_panel_step<NQ, Q0, 2>(P, vp, gk, Tr, bp, si, sb, sj);
+        if (steps > 3) strip_panel_step<NQ, Q0, 3>(P, vp, gk, Tr, bp, si, sb, sj);
 #pragma unroll
         for (int q = Q0; q < NQ; ++q) { C[q][0] = P[q]; V[q] = P[q]; }
         // V: below the pivots the panel's columns ARE the reflectors; in the pivot quad the diagonal takes v's pivot entries,
@@ -362,13 +357,8 @@ __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc,
     if (r_rows && sj >= si && col0 <= nc) dst[0] = C[Q0][0];
     // (a panel with fewer than four pivots is the last one: c sits in its block, nothing lies to the right of it)
     if (NT > 0 && steps == 4) {
-        // T (upper triangular: H_0 .. H_3 = I - V T V^T) came out of the steps; as a strip, negated: -T[k][i] at lane (k = si, ., i = sj)
-        double Ts = 0.0;
-        Ts = si == 0 ? (sj == 0 ? T[0][0] : sj == 1 ? T[0][1] : sj == 2 ? T[0][2] : T[0][3]) : Ts;
-        Ts = si == 1 ? (sj == 1 ? T[1][1] : sj == 2 ? T[1][2] : sj == 3 ? T[1][3] : 0.0) : Ts;
-        Ts = si == 2 ? (sj == 2 ? T[2][2] : sj == 3 ? T[2][3] : 0.0) : Ts;
-        Ts = si == 3 ? (sj == 3 ? T[3][3] : 0.0) : Ts;
-        Ts = -Ts;
+        // T came out of the steps, row si in this lane; as a strip, negated: -T[k][i] at lane (k = si, ., i = sj)
+        const double Ts = -(sj == 0 ? Tr[0] : sj == 1 ? Tr[1] : sj == 2 ? Tr[2] : Tr[3]);
         NIN_SUB(ST, 1);   // T
         // W[cb] = V^T C[.][cb]: NT independent accumulation chains (blocks past the live ones hold zeros: harmless)
         double W[NT + 1];
@@ -414,9 +404,16 @@ __device__ __forceinline__ double strip_factor(double (&C)[NQ][NCB], int nc, int
     const double eye = si == sj ? 1.0 : 0.0;                     // the 4 x 4 identity in every quad
     const int n_panels = (nc + 3) >> 2;
     static_assert(NQ >= 3 && NCB >= 2 && NCB <= 12, "up to three generations of panels");
-    for (int p = 0; p < (n_panels < 4 ? n_panels : 4); ++p) strip_panel<NQ, NCB, 0, NCB - 1>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
+    // two instantiations per generation: the later two panels of each sweep two zero blocks fewer (-13 % MFMAs: tet40 1.35 -> 1.32 ms)
+    for (int p = 0; p < (n_panels < 2 ? n_panels : 2); ++p) strip_panel<NQ, NCB, 0, NCB - 1>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
+    if constexpr (NCB > 2) {
+        for (int p = 2; p < (n_panels < 4 ? n_panels : 4); ++p) strip_panel<NQ, NCB, 0, NCB - 3>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
+    }
     if constexpr (NCB > 4) {
-        for (int p = 4; p < (n_panels < 8 ? n_panels : 8); ++p) strip_panel<NQ, NCB, 1, NCB - 5>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
+        for (int p = 4; p < (n_panels < 6 ? n_panels : 6); ++p) strip_panel<NQ, NCB, 1, NCB - 5>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
+    }
+    if constexpr (NCB > 6) {
+        for (int p = 6; p < (n_panels < 8 ? n_panels : 8); ++p) strip_panel<NQ, NCB, 1, NCB - 7>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
     }
     if constexpr (NCB > 8) {
         for (int p = 8; p < n_panels; ++p) strip_panel<NQ, NCB, 2, NCB - 9>(C, p, nc, si, sb, sj, eye, Rm, RP, ST);
