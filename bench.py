@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--no-other-meshes", action="store_true",
                     help="skip the GLS-on-tet/mixed-mesh context (profiling runs: keeps per-kernel averages clean)")
     ap.add_argument("--no-extras", action="store_true", help="skip the IDW/LS context numbers and the e2e timing")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end interpolate() timing (profiling runs: it launches the kernels in four pieces, which would dilute per-dispatch averages)")
     ap.add_argument("--check", action="store_true",
                     help="(small --edge only) rank 0 recomputes the whole mesh on its GPU and compares the gathered triplets")
     args = ap.parse_args()
@@ -432,15 +434,17 @@ def main():
             del out, nws
             torch.cuda.empty_cache()
             # host-buffer (PCIe-inclusive) path, never `value`: the first call also pins its output buffers (recycled afterwards)
-            t0 = time.time()
-            W, _ = I.interpolate("u", args.method)
-            line["e2e_interpolate_first_s"] = round(time.time() - t0, 3)
-            del W
-            t0 = time.time()
-            W, _ = I.interpolate("u", args.method)
-            line["e2e_interpolate_s"] = round(time.time() - t0, 3)
-            line["e2e_nnz"] = int(W.nnz)
-            del W, I
+            if not args.no_e2e:
+                t0 = time.time()
+                W, _ = I.interpolate("u", args.method)
+                line["e2e_interpolate_first_s"] = round(time.time() - t0, 3)
+                del W
+                t0 = time.time()
+                W, _ = I.interpolate("u", args.method)
+                line["e2e_interpolate_s"] = round(time.time() - t0, 4)
+                line["e2e_nnz"] = int(W.nnz)
+                del W
+            del I
             # one row per single-GPU entry of BASELINE.json's `configs` (kernel only, HIP events): [1] IDW and
             # [2] GLS on the 1 M-cell hexahedron mesh, [3] GLS on the 10 M-cell hex | pyramid | tet mix; plus the Kuhn-tet
             # mesh the block kernel is tuned on.  ([0] is the reference's CPU plumbing case, [4] the 8-GPU run: --gpus 8.)

@@ -10,11 +10,11 @@ OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-other-meshes > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || { echo "stats pass failed"; tail -5 $OUT/stats.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-other-meshes --no-e2e > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || { echo "stats pass failed"; tail -5 $OUT/stats.err; exit 1; }
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-other-meshes > $OUT/pmc$i.json 2> $OUT/pmc$i.err || { echo "pmc pass $i failed"; tail -5 $OUT/pmc$i.err; exit 1; }
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-other-meshes --no-e2e > $OUT/pmc$i.json 2> $OUT/pmc$i.err || { echo "pmc pass $i failed"; tail -5 $OUT/pmc$i.err; exit 1; }
 done
 # the block kernel by size class on the mixed and Kuhn-tet meshes (BASELINE config [3] at size: mixed10m)
 NIN_GRID_BUILD=device timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mixed_tet -- python3 tools/time_methods.py mixed tet40 wedge60 mixed10m > $OUT/methods_by_mesh.txt 2> $OUT/mixed_tet.err || { echo "mixed/tet pass failed"; tail -5 $OUT/mixed_tet.err; }
