@@ -439,11 +439,14 @@ def main():
                 W, _ = I.interpolate("u", args.method)
                 line["e2e_interpolate_first_s"] = round(time.time() - t0, 3)
                 del W
-                t0 = time.time()
-                W, _ = I.interpolate("u", args.method)
-                line["e2e_interpolate_s"] = round(time.time() - t0, 4)
-                line["e2e_nnz"] = int(W.nnz)
-                del W
+                best = 1e30
+                for _ in range(3):      # steady state: the page-locked buffers of the first call are recycled
+                    t0 = time.time()
+                    W, _ = I.interpolate("u", args.method)
+                    best = min(best, time.time() - t0)
+                    line["e2e_nnz"] = int(W.nnz)
+                    del W
+                line["e2e_interpolate_s"] = round(best, 4)
             del I
             # one row per single-GPU entry of BASELINE.json's `configs` (kernel only, HIP events): [1] IDW and
             # [2] GLS on the 1 M-cell hexahedron mesh, [3] GLS on the 10 M-cell hex | pyramid | tet mix; plus the Kuhn-tet
