@@ -357,10 +357,11 @@ int nin_grid_to_device(nin_grid *g, int device) {
     // ---- GLS launch plan: bin nodes by the size of their least-squares system (classified on the device) ----
     g->node_class.assign((size_t)P, 0);
     std::vector<std::vector<int32_t>> lists(kGlsClasses);
-    std::vector<int32_t> hex8_list, mfw_list[3];
+    std::vector<int32_t> hex8_list, mfw_list[3], small_list[3];
     // debugging switches: keep nodes away from the hex8 kernel (bit 0) / the one-wavefront multifrontal kernel (bit 1)
     const int use_group = (getenv("NIN_GLS_NO_GROUP") == nullptr ? 1 : 0) | (getenv("NIN_GLS_NO_MFW") == nullptr ? 2 : 0) |
-                          (getenv("NIN_GLS_NO_MFW_GENERAL") == nullptr ? 4 : 0);   // (bit 2: the multifrontal kernel's general kind)
+                          (getenv("NIN_GLS_NO_MFW_GENERAL") == nullptr ? 4 : 0) |   // (bit 2: the multifrontal kernel's general kind)
+                          (getenv("NIN_GLS_NO_SMALL") == nullptr ? 8 : 0);          // (bit 3: the one-wavefront dense kernel for small nodes)
     const bool force_global = getenv("NIN_GLS_FORCE_GLOBAL") != nullptr;   // testing switch: systems in global scratch
     int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0}, cols_max[kGlsClasses] = {0};
     {
@@ -383,6 +384,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         const uint8_t c = g->node_class[p];
         if (c == 255) hex8_list.push_back((int32_t)p);
         else if (c >= 252 && c <= 254) mfw_list[254 - c].push_back((int32_t)p);
+        else if (c >= 249 && c <= 251) small_list[c - 249].push_back((int32_t)p);
         else lists[c].push_back((int32_t)p);
     }
     for (int c = 0; c < kGlsClasses; ++c) {
@@ -418,6 +420,12 @@ int nin_grid_to_device(nin_grid *g, int device) {
             if (launch_mfw_desc(d.v, d.mfw[i].nodes, d.mfw[i].count, d.mfw_desc[i], nullptr)) return fail(NIN_EHIP, "mfw descriptor kernel");
         }
     }
+    for (int i = 0; i < 3; ++i) {
+        d.small[i].count = (int32_t)small_list[i].size();
+        const int32_t *lp = nullptr;
+        if (d.small[i].count && (rc = dev_upload(d, &lp, small_list[i]))) return rc;
+        d.small[i].nodes = const_cast<int32_t *>(lp);
+    }
     d.gls_too_large = rows_max[kGlsClasses - 1] > 1024;
     if ((rc = dev_alloc(d, &d.gls_queue, (size_t)kGlsQueueInts))) return rc;
     if (d.gls[kGlsClasses - 1].count) {
@@ -436,6 +444,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         for (int c = 0; c < kGlsClasses; ++c) cut(c, lists[c]);
         cut(kGlsClasses, hex8_list);
         for (int i = 0; i < 3; ++i) cut(kGlsClasses + 1 + i, mfw_list[i]);
+        for (int i = 0; i < 3; ++i) cut(kGlsClasses + 4 + i, small_list[i]);
         const char *mn = getenv("NIN_E2E_MIN_NODES");                                // (tests: the pipeline on small meshes too)
         d.chunkable = P >= (mn ? atoll(mn) : 64 * 1024) && P >= 64 * K && getenv("NIN_E2E_NO_PIPELINE") == nullptr;   // small meshes: one piece
     }
@@ -519,6 +528,8 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
             rc = launch_hex8(d, d.hex8.nodes, d.hex8_desc, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             for (int i = 0; i < 3 && !rc; ++i)
                 rc = launch_mfw(d, d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, i, add_neumann, dev_csr_data, dev_neumann_ws, stream);
+            for (int i = 0; i < 3 && !rc; ++i)
+                rc = launch_gls_small(d.v, d.small[i].nodes, d.small[i].count, i, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             for (int c = 0; c < kGlsClasses && !rc; ++c) {
                 rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             }
@@ -532,11 +543,12 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     HIP_TRY(hipMemsetAsync(dev_csr_data, 0, (size_t)d.nnz_e * 8, stream));
     HIP_TRY(hipMemsetAsync(dev_neumann_ws, 0, (size_t)P * 8, stream));
     if (n_targets == 0) return NIN_OK;
-    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 4 : 1);
+    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 7 : 1);
     for (int64_t i = 0; i < n_targets; ++i) {
         int c = method == NIN_METHOD_GLS ? g->node_class[targets[i]] : 0;
         if (c == 255) c = kGlsClasses;   // the hex8 kernel's class
         else if (c >= 252 && c <= 254) c = kGlsClasses + 1 + (254 - c);   // the one-wavefront multifrontal kernel, kind 0 / 1 / 2
+        else if (c >= 249 && c <= 251) c = kGlsClasses + 4 + (c - 249);   // the small-node kernel, kind 0 / 1 / 2
         lists[c].push_back((int32_t)targets[i]);
     }
     // one device buffer for all class lists, filled before the first launch: a per-class allocate / copy / free
@@ -576,6 +588,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_hex8(d, dl, ddesc, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
+        else if ((int)c >= kGlsClasses + 4) rc = launch_gls_small(d.v, dl, cnt, (int)c - kGlsClasses - 4, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c > kGlsClasses)
             rc = launch_mfw(d, dl, dmfw + kMfwDescWords * (first[c] - first[kGlsClasses + 1]), cnt, (int)c - kGlsClasses - 1, add_neumann,
                             dev_csr_data, dev_neumann_ws, stream);
@@ -720,6 +733,10 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
         const int32_t b = d.chunk_off[kGlsClasses + 1 + i][k], n = d.chunk_off[kGlsClasses + 1 + i][k + 1] - b;
         if (n > 0) rc = launch_gls_mfw(d.v, d.mfw[i].nodes + b, d.mfw_desc[i] + (size_t)kMfwDescWords * b, n, i, 1, out, nws,
                                        d.gls_queue + 5 + i, stream);
+    }
+    for (int i = 0; i < 3 && !rc; ++i) {
+        const int32_t b = d.chunk_off[kGlsClasses + 4 + i][k], n = d.chunk_off[kGlsClasses + 4 + i][k + 1] - b;
+        if (n > 0) rc = launch_gls_small(d.v, d.small[i].nodes + b, n, i, 1, out, nws, stream);
     }
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         const int32_t b = d.chunk_off[c][k], n = d.chunk_off[c][k + 1] - b;
@@ -949,7 +966,7 @@ int nin_host_free(void *ptr) {
     return NIN_OK;
 }
 
-int nin_gls_plan(const nin_grid *g, int64_t counts[9]) {
+int nin_gls_plan(const nin_grid *g, int64_t counts[12]) {
     if (!g || !counts) return fail(NIN_EINVAL, "NULL argument");
     if (g->d.device < 0 || g->d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
     for (int c = 0; c < kGlsClasses; ++c) counts[c] = g->d.gls[c].count;
@@ -957,6 +974,7 @@ int nin_gls_plan(const nin_grid *g, int64_t counts[9]) {
     counts[6] = g->d.mfw[0].count;
     counts[7] = g->d.mfw[1].count;
     counts[8] = g->d.mfw[2].count;
+    for (int i = 0; i < 3; ++i) counts[9 + i] = g->d.small[i].count;
     return NIN_OK;
 }
 

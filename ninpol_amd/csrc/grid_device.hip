@@ -574,6 +574,11 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
         }
         if (kind == 2 && (use_group & 4)) { node_class[p] = 252; return; }
     }
+    // small nodes (in practice: boundary nodes): the one-wavefront dense kernel, lane = row (kernels_gls_mfw.hip, nin_gls_small_kernel)
+    if ((use_group & 8) && !force_global && g.dim == 3 && ne <= 12 && nf <= 48 && ne + 3 * (nf - nbf) + nbf <= 64) {
+        node_class[p] = ne <= 4 ? 249 : ne <= 8 ? 250 : 251;
+        return;
+    }
     int64_t bytes, rows, cols;
     const int c = gls_node_class(ne, nf, nbf, force_global != 0, &bytes, &rows, &cols);
     node_class[p] = (uint8_t)c;

@@ -907,6 +907,197 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
     }
 }
 
+// ---- small nodes: the WHOLE system in one wavefront's registers, lane = row ---------------------------------------------
+// What neither the cube-node kernel nor the fronts above take and is small -- in practice the BOUNDARY nodes that carry a
+// Neumann flag: 4 cells, 4 internal + 4 boundary faces on a face of a hexahedron box (20 x 13), 2 cells on its edges, half a
+// truncated octahedron on a tetrahedron boundary -- used to go to the block kernel: a workgroup, an LDS image of the system,
+// a plan built with LDS atomics, for 20 rows -- 68 k SIMD cycles a node, more than a 96 x 37 Kuhn node takes here.  This kernel
+// needs no plan: up to DM cells (3 DM + 1 columns) and up to 64 rows, lane r IS row r -- the cell rows, then three rows per
+// internal face (in fsup order), then the Neumann rows (gls.pyx:269-281, 293-356, 394-416) -- built in the lane from a per-face
+// record staged in LDS, the columns static register indices, and the row-lane Householder of the dense phase above (rows_step:
+// one reduction per column, four columns at a time) does the rest.  Same zero-row rule as every GLS kernel (no internal face,
+// fewer rows than unknowns, a zero pivot column through the NaN test).  A wave looks at 64 list entries at a time and gives
+// Dirichlet boundary nodes (gls.pyx:165-166) their zero row right there; the others it computes one after the other.
+constexpr int kSmallMaxFaces = 48;
+template <int DM>
+struct SmallDims {
+    static constexpr int NP = 3 * DM, RP = NP + 1;
+    static constexpr int LDS_Y = NP * RP, LDS_W = LDS_Y + NP + 4, LDS_F = LDS_W + ((DM + 1) & ~1),   // R rows | y | weights | face records
+                         FREC = 14,                                                                   // per face: 12 values + (Ia, Ib) in one more + pad
+                         LDS_PER_WAVE = LDS_F + FREC * kSmallMaxFaces;
+};
+
+template <int DM>
+__global__ __launch_bounds__(256, (DM <= 4 ? 4 : DM <= 8 ? 3 : 2)) void nin_gls_small_kernel(GridView g, const int32_t *__restrict__ nodes,
+                                                                                             int32_t count, int add_neumann,
+                                                                                             double *__restrict__ out,
+                                                                                             double *__restrict__ nws) {
+    using Dm = SmallDims<DM>;
+    constexpr int NP = Dm::NP, RP = Dm::RP;
+    __shared__ double lds_all[4][Dm::LDS_PER_WAVE];
+    const int lane = threadIdx.x & 63;
+    double *const Rm = lds_all[threadIdx.x >> 6];
+    double *const yb = Rm + Dm::LDS_Y, *const wbuf = Rm + Dm::LDS_W, *const frec = Rm + Dm::LDS_F;
+    // a wave's 64 entries per round lie n_waves apart: boundary nodes that are computed come in runs (a Neumann plane is one
+    // run of the list), and a run must spread over all waves instead of filling a few of them
+    const int64_t n_waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t tile = wave; tile < count; tile += n_waves * 64) {
+        unsigned long long todo;
+        {
+            const int64_t i = tile + lane * n_waves;
+            const bool in = i < count;
+            const int32_t pl = in ? (nodes ? nodes[i] : (int32_t)i) : 0;
+            const int fll = in ? (int)g.flags[pl] : 0;
+            const bool dirichlet = in && (fll & 1) && !(fll & 2);
+            if (dirichlet) {
+                const int32_t b0 = g.esup_ptr[pl], b1 = g.esup_ptr[pl + 1];
+                for (int32_t j = b0; j < b1; ++j) out[j] = 0.0;
+                nws[pl] = 0.0;
+            }
+            todo = __ballot(in && !dirichlet);
+        }
+        while (todo) {
+            const int bit = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int64_t idx = tile + bit * n_waves;
+            const int32_t p = __builtin_amdgcn_readfirstlane(nodes ? nodes[idx] : (int32_t)idx);
+            const int32_t eb = __builtin_amdgcn_readfirstlane(g.esup_ptr[p]), ne = __builtin_amdgcn_readfirstlane(g.esup_ptr[p + 1]) - eb;
+            const int32_t fb = __builtin_amdgcn_readfirstlane(g.fsup_ptr[p]), nf = __builtin_amdgcn_readfirstlane(g.fsup_ptr[p + 1]) - fb;
+            const bool is_neu = (__builtin_amdgcn_readfirstlane((int)g.flags[p]) & 2) != 0;
+            const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1], xv2 = g.coords[3 * (size_t)p + 2];
+            // lane i < ne: cell i; lane f < nf: face f
+            const int32_t mycell = lane < ne ? g.esup[eb + lane] : -1;
+            const bool face_lane = lane < nf;
+            const size_t f = face_lane ? (size_t)g.fsup[fb + lane] : 0;
+            const int32_t ca = face_lane ? g.face_cells[2 * f] : -1, cb = face_lane ? g.face_cells[2 * f + 1] : -1;
+            const bool internal = face_lane && cb >= 0;
+            const unsigned long long m_int = __ballot(internal), m_bnd = __ballot(face_lane && !internal);
+            const int n_if = __popcll(m_int), n_bf = __popcll(m_bnd);
+            const int nc = 3 * ne, m = ne + 3 * n_if + (is_neu ? n_bf : 0);
+            if (n_if == 0 || m < nc) {                            // (wave-uniform) outside the parity set: the zero row
+                if (lane < ne) out[eb + lane] = 0.0;
+                if (lane == 0) nws[p] = 0.0;
+                continue;
+            }
+            // ---- a record per face: (Ia, Ib), -K_a N, +K_b N, T, tau U (internal) or -K_a N (boundary, Neumann nodes) ---------
+            int Ia = 0, Ib = 0;                                  // positions of the face's two cells in the esup row
+            for (int q = 0; q < ne; ++q) {                        // (every lane takes part: a shuffle reads active lanes only)
+                const int32_t cq = __shfl(mycell, q);
+                Ia = cq == ca ? q : Ia;
+                Ib = cq == cb ? q : Ib;
+            }
+            if (face_lane) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int rec = internal ? __popcll(m_int & below) : n_if + __popcll(m_bnd & below);
+                double *fr = frec + Dm::FREC * rec;
+                const double N0 = (double)g.face_normal[3 * f + 0], N1 = (double)g.face_normal[3 * f + 1], N2 = (double)g.face_normal[3 * f + 2];
+                const double *Ka = g.perm + 9 * (size_t)ca;
+                fr[0] = -(Ka[0] * N0 + Ka[1] * N1 + Ka[2] * N2);
+                fr[1] = -(Ka[3] * N0 + Ka[4] * N1 + Ka[5] * N2);
+                fr[2] = -(Ka[6] * N0 + Ka[7] * N1 + Ka[8] * N2);
+                if (internal) {
+                    const double *Kb = g.perm + 9 * (size_t)cb;
+                    fr[3] = Kb[0] * N0 + Kb[1] * N1 + Kb[2] * N2;
+                    fr[4] = Kb[3] * N0 + Kb[4] * N1 + Kb[5] * N2;
+                    fr[5] = Kb[6] * N0 + Kb[7] * N1 + Kb[8] * N2;
+                    const double T0 = xv0 - g.face_center[3 * f + 0], T1 = xv1 - g.face_center[3 * f + 1], T2 = xv2 - g.face_center[3 * f + 2];
+                    const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+                    const double da = g.diff_mag[ca], db = g.diff_mag[cb];
+                    double eta = 0.0;
+                    eta = da > eta ? da : eta;
+                    eta = db > eta ? db : eta;
+                    const double tj = face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
+                    fr[6] = T0; fr[7] = T1; fr[8] = T2;
+                    fr[9] = tj * U0; fr[10] = tj * U1; fr[11] = tj * U2;
+                }
+                reinterpret_cast<int32_t *>(fr + 12)[0] = Ia;
+                reinterpret_cast<int32_t *>(fr + 12)[1] = internal ? Ib : -1;
+            }
+            wave_lds_sync();
+            // ---- lane r builds row r: two cell slots (Ia, Ib) carry three entries each, c = 1 on the cell rows ---------------
+            double b[NP], a_unused[NP], ca_unused = 0.0, cbv = 0.0, dod[3] = {0.0, 0.0, 0.0};
+            {
+                int Ra = -1, Rb = -1;                             // the two cell slots of THIS lane's row
+                double va[3] = {0.0, 0.0, 0.0}, vb[3] = {0.0, 0.0, 0.0};
+                if (lane < ne) {                                   // gls.pyx:269-281
+                    const size_t c = (size_t)mycell;
+                    va[0] = g.centroids[3 * c + 0] - xv0; va[1] = g.centroids[3 * c + 1] - xv1; va[2] = g.centroids[3 * c + 2] - xv2;
+                    dod[0] = va[0]; dod[1] = va[1]; dod[2] = va[2];
+                    Ra = lane;
+                    cbv = 1.0;
+                } else if (lane < ne + 3 * n_if) {                 // gls.pyx:340-356: [-B_a | +B_b], B = [K N; T; tau U]
+                    const int x = lane - ne, q = (x * 43) >> 7, k = x - 3 * q;
+                    const double *fr = frec + Dm::FREC * q;
+                    Ra = reinterpret_cast<const int32_t *>(fr + 12)[0];
+                    Rb = reinterpret_cast<const int32_t *>(fr + 12)[1];
+                    const int oa = k == 0 ? 0 : k == 1 ? 6 : 9, ob = k == 0 ? 3 : k == 1 ? 6 : 9;
+                    const double sa = k == 0 ? 1.0 : -1.0;         // (record: -K_a N already negated; T, tau U stored once)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) { va[t] = sa * fr[oa + t]; vb[t] = fr[ob + t]; }
+                } else if (lane < m) {                             // gls.pyx:394-416: -(K N) of the boundary face's cell
+                    const double *fr = frec + Dm::FREC * (n_if + lane - ne - 3 * n_if);
+                    Ra = reinterpret_cast<const int32_t *>(fr + 12)[0];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) va[t] = fr[t];
+                }
+#pragma unroll
+                for (int sl = 0; sl < DM; ++sl) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) b[3 * sl + t] = sl == Ra ? va[t] : (sl == Rb ? vb[t] : 0.0);
+                }
+            }
+            // ---- Householder, one reduction per column (rows_step), R through LDS ----------------------------------------------
+            Reflector h = reflector(rl64(b[0], 0), wave_allsum(b[0] * b[0]));
+            for (int k = 0; k < ne; ++k) rows_block<NP, false>(a_unused, b, ca_unused, cbv, h, k, nc, lane, Rm, RP);
+            if (lane < nc) Rm[lane * RP + nc] = cbv;
+            const double cbl = lane >= nc ? cbv : 0.0;
+            const double rr = wave_allsum(cbl * cbl);
+            wave_lds_sync();
+            {
+                const int li = lane < nc ? lane : 0;
+                double ct = lane < nc ? Rm[li * RP + nc] : 0.0;
+                const double ri = fast_rcp(Rm[li * RP + li]);
+                const double *Rl = Rm + li * RP;
+                int kb = (nc - 1) & ~3;
+                double c4[4], n4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c4[j] = (lane < nc && kb + j < nc) ? Rl[kb + j] : 0.0;
+                for (; kb >= 0; kb -= 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) n4[j] = (lane < nc && kb >= 4) ? Rl[kb - 4 + j] : 0.0;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const int k = kb + j;
+                        if (k < nc) {
+                            const double yk = rl64(ct * ri, k);
+                            ct = lane < k ? fma(-yk, c4[j], ct) : ct;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c4[j] = n4[j];
+                }
+                if (lane < nc) yb[lane] = ct * ri;
+            }
+            wave_lds_sync();
+            {
+                const int ld = lane < ne ? lane : 0;
+                const double ro = 1.0 - fma(dod[2], yb[3 * ld + 2], fma(dod[1], yb[3 * ld + 1], dod[0] * yb[3 * ld]));
+                double w = ro * fast_rcp(rr);
+                w = (rr > 0.0 && __builtin_isfinite(w)) ? w : 0.0;
+                if (lane < ne) wbuf[lane] = w;
+            }
+            wave_lds_sync();
+            {
+                const double nwv = is_neu ? wbuf[ne - 1] : 0.0;          // gls.pyx:470-472: the LAST cell's weight
+                const double addv = add_neumann ? nwv : 0.0;
+                if (lane < ne) out[eb + lane] = wbuf[lane] + addv;
+                if (lane == 0) nws[p] = nwv;
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
 __global__ void k_mfw_desc(GridView g, const int32_t *__restrict__ nodes, int32_t count, uint32_t *__restrict__ desc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -949,6 +1140,19 @@ int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc
     else if (no_strips) NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, true, false, false);
     else NIN_MFW_LAUNCH(kMfwMaxFronts, kMfwMaxDense, true, false, true);
 #undef NIN_MFW_LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// `kind`: 0 / 1 / 2 = at most 4 / 8 / 12 cells
+int launch_gls_small(const GridView &g, const int32_t *nodes, int32_t count, int kind, int add_neumann, double *out, double *nws,
+                     hipStream_t stream) {
+    if (count <= 0) return 0;
+    int64_t blocks = ((int64_t)count + 255) / 256;              // a wave looks at 64 list entries per round
+    const int64_t cap = 256 * (kind == 0 ? 4 : kind == 1 ? 3 : 2) * 2;
+    if (blocks > cap) blocks = cap;
+    if (kind == 0) hipLaunchKernelGGL(nin_gls_small_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, count, add_neumann, out, nws);
+    else if (kind == 1) hipLaunchKernelGGL(nin_gls_small_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, count, add_neumann, out, nws);
+    else hipLaunchKernelGGL(nin_gls_small_kernel<12>, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, count, add_neumann, out, nws);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

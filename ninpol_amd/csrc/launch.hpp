@@ -38,6 +38,9 @@ int launch_mfw_desc(const GridView &g, const int32_t *nodes, int32_t count, uint
 int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int kind, int add_neumann,
                    double *out, double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_mfw();
+// the one-wavefront dense kernel for small nodes (kernels_gls_mfw.hip): kind 0 / 1 / 2 = at most 4 / 8 / 12 cells, at most 64 rows
+int launch_gls_small(const GridView &g, const int32_t *nodes, int32_t count, int kind, int add_neumann, double *out, double *nws,
+                     hipStream_t stream);
 // out[j] += nws[row(j)] for IDW / LS is a no-op (their neumann_ws is 0): nothing to launch.
 
 // CSR finish (interpolator.pyx:622-624): count non-zeros per row, scan, compact

@@ -176,6 +176,7 @@ def test_gpu_generic_kernel_on_hex(oracle_lib, monkeypatch, no_mfw):
     monkeypatch.setenv("NIN_GLS_NO_GROUP", "1")
     if no_mfw:
         monkeypatch.setenv("NIN_GLS_NO_MFW", "1")
+        monkeypatch.setenv("NIN_GLS_NO_SMALL", "1")   # (44 rows: the small-node kernel would take them)
     mesh = M.hex_mesh(9, jitter=0.15, seed=5)
     M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(0, 1.0), seed=2)
     o = oracle_lib.OracleInterpolator("port", threads=2)
@@ -208,6 +209,7 @@ def test_gpu_block_kernel_where_mfw_would_run(oracle_lib, monkeypatch, kind):
     for off in (False, True):
         if off:
             monkeypatch.setenv("NIN_GLS_NO_MFW", "1")
+            monkeypatch.setenv("NIN_GLS_NO_SMALL", "1")
         I = _interp()
         I.load_mesh(mesh_obj=mesh)
         I.grid.to_device(0)
@@ -415,7 +417,9 @@ _GLS_ROUTES = {
     "mfw_row_lanes": ("NIN_MFW_NO_STRIPS",),                              # its second form (round 2's default) where the strip form runs now
     "mfw_small_strips": ("NIN_GLS_NO_GROUP", "NIN_MFW_SMALL_STRIPS"),     # the strip form in the small instantiation (wedge / cube nodes)
     "no_general_kind": ("NIN_GLS_NO_MFW_GENERAL",),                       # general-kind nodes -> block kernel
-    "block_only": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"),                 # block kernel, 1 / 2 / 4 / 8 wavefronts per node
+    "no_small_kernel": ("NIN_GLS_NO_SMALL",),                             # boundary nodes -> block kernel (round 2's route)
+    "small_where_it_fits": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"),        # the small-node kernel for every node of <= 12 cells and <= 64 rows
+    "block_only": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_SMALL"),   # block kernel, 1 / 2 / 4 / 8 wavefronts per node
     "global_scratch": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_FORCE_GLOBAL"),   # the wave kernel
 }
 
@@ -453,8 +457,11 @@ def test_gpu_gls_degenerate_zero_pivot_column(monkeypatch, kind):
     assert (d["mfw_general"] > 0) == (kind == "mixed")
     assert plans["no_cube_kernel"]["hex8"] == 0 and plans["no_cube_kernel"]["mfw_small"] >= d["hex8"]
     assert plans["no_general_kind"]["mfw_general"] == 0
+    small = ("small4", "small8", "small12")
+    assert sum(d[k] for k in small) > 0 and all(plans["no_small_kernel"][k] == 0 for k in small)
+    assert sum(plans["small_where_it_fits"][k] for k in small) >= sum(d[k] for k in small) + (d["hex8"] if kind == "hex" else 0)
     for route in ("block_only", "global_scratch"):
-        assert all(plans[route][k] == 0 for k in ("hex8", "mfw_large", "mfw_small", "mfw_general")), route
+        assert all(plans[route][k] == 0 for k in ("hex8", "mfw_large", "mfw_small", "mfw_general") + small), route
     assert all(sum(p.values()) == I.grid.n_points for p in plans.values())
 
 
@@ -482,7 +489,7 @@ def test_gpu_gls_fan_permeability(oracle_lib, n):
     # the same nodes through the generic kernels (cube-node kernel off): the bound is a property of the case, not of a kernel
     if n == 32:
         import os
-        for switches in (("NIN_GLS_NO_GROUP",), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW")):
+        for switches in (("NIN_GLS_NO_GROUP",), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_SMALL")):
             for sw in switches:
                 os.environ[sw] = "1"
             try:
