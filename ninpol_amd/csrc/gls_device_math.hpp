@@ -41,13 +41,30 @@ struct House {
 // The same without the x = 0 branch.  x = 0, alpha != 0 needs none: beta = -alpha, v = (2 alpha, 0), H flips the sign of
 // the pivot row -- orthogonal all the same.  A column that is zero altogether (S = 0) turns into NaNs here, which the
 // caller's final finiteness test maps to the zero row a rank-deficient system gets anyway.
+#ifdef NIN_HOUSE_ONE_STEP
+// one correction step each (kernels_gls_hex8mf.hip): the cubic step takes v_rsq_f64's 2^-26 to rounding level, the Newton step v_rcp_f64's to ~2^-52
+__device__ __forceinline__ double fast_rcp1(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+__device__ __forceinline__ double fast_rsqrt1(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+    const double e = fma(-s * y, y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+#define NIN_HOUSE_RCP fast_rcp1
+#define NIN_HOUSE_RSQRT fast_rsqrt1
+#else
+#define NIN_HOUSE_RCP fast_rcp
+#define NIN_HOUSE_RSQRT fast_rsqrt
+#endif
 __device__ __forceinline__ House house_unguarded(double alpha, double ss) {
     const double S = fma(alpha, alpha, ss);
-    const double rs = fast_rsqrt(S), sq = S * rs;
+    const double rs = NIN_HOUSE_RSQRT(S), sq = S * rs;
     House h;
     h.beta = -copysign(sq, alpha);
     h.vp = alpha - h.beta;
-    h.g = fast_rcp(fma(fabs(alpha), sq, S));
+    h.g = NIN_HOUSE_RCP(fma(fabs(alpha), sq, S));
     h.rinv = -(h.g * h.vp);
     return h;
 }

@@ -32,9 +32,14 @@
 // as the dense 16-lanes-per-node kernel of round 1 (41 ms, removed) was.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "device_grid.hpp"
+// the reflector scalars with ONE correction step behind the hardware seeds in this file (gls_device_math.hpp): the cubic step
+// takes v_rsq_f64's 2^-26 to rounding level, the Newton step v_rcp_f64's to ~2^-52 -- an ulp-level departure of H from
+// orthogonality; 90 FP64 instructions per pass less (row-scaled error against the oracle 3.7e-14 -> 5.5e-14, tools/err_hex.py)
+#define NIN_HOUSE_ONE_STEP
 #include "gls_device_math.hpp"
 #include "hex8_desc.hpp"
 #include "launch.hpp"
@@ -282,6 +287,9 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
         cur.level3(g);
     }
 #ifdef NIN_MF_STAMPS
+#ifndef NIN_MF_STAMP_PASS
+#define NIN_MF_STAMP_PASS 8
+#endif
     unsigned long long stamps[8];
     int n_stamp = 0, pass_no = 0;
 #define NIN_MF_STAMP() do { if (n_stamp < 8) { __builtin_amdgcn_sched_barrier(0); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -464,13 +472,420 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
         wave_lds_sync();
         NIN_MF_STAMP();                                   // 7: weights stored
 #ifdef NIN_MF_STAMPS
-        if (blockIdx.x == 0 && threadIdx.x == 0 && ++pass_no == 8)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && ++pass_no == NIN_MF_STAMP_PASS)
             for (int i = 0; i < 8; ++i) nws[nodes[i]] = (double)(stamps[i] - stamps[0]);   // (diagnostic build: clobbers neumann_ws of the first 8 listed nodes)
 #endif
         cur = nx;
         wg = wg_next;
         wg_next = wg_lo + (int32_t)__builtin_amdgcn_readfirstlane(nx.ticket);
     }
+}
+
+// ---- the same node on TWO wavefronts per SIMD ------------------------------------------------------------------------------
+// A lone wavefront cannot keep the FP64 pipe busy (tools/micro_mfma64.hip: one wave issues a v_fma_f64 every 8.5 cycles, two
+// waves together one every 5.9), and the kernel above is one wave per SIMD because its peak -- the end of phase 1, where the
+// finished fill rows, the panel, a block in flight and the face records coexist -- is ~340 registers.  This variant fits 256:
+//   * phase 1 takes the odd-slot blocks ONE COLUMN at a time (10 doubles in flight, not 30), and the first 35 finished fill
+//     entries of a lane (c, odd slot 0, the first column of slot 1) wait in LDS -- lane-private slots, [slot][lane], no
+//     conflicts, no synchronisation -- until the panel and the face records are gone;
+//   * phase 2 computes each column's dot where it is used (no array of partial dots across the scalar chain: the OTHER wave
+//     fills that latency now), with u and s in the LDS slots the fill entries have left;
+//   * plain loads at the top of a pass, static round-robin over the groups (the other wave covers the latency; nothing is in
+//     flight that the compiler does not know about).
+// Same arithmetic, same order of the Householder steps: results differ from the kernel above by rounding only.
+#ifdef NIN_W2_FENCE_COLUMNS
+#define NIN_W2_COLUMN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define NIN_W2_COLUMN_FENCE() do { } while (0)
+#endif
+constexpr int W2_SLOTS = 35;                                  // 64-lane slots of 8 B per wave
+constexpr int W2_WAVE_DOUBLES = W2_SLOTS * 64 + NPW * 8 + 64;  // + the weights' staging + two dword rows (19 456 B per wave: two workgroups per CU)
+
+template <int K>
+__device__ __forceinline__ void p2_step_lean(double (&C)[NR][NC], double (&rinvq)[3], int l) {
+    constexpr int Q = K / 4, LAM = K % 4;
+    // partial dots that are formed BEFORE the step's scalars (they do not need them, and fill that chain's latency): as many
+    // as the registers allow -- at step 0 the tile is complete and only a few fit, from step 1 on the retired column pays for all
+#ifndef NIN_W2_ND0
+#define NIN_W2_ND0 5
+#endif
+    constexpr int ND = (K == 0) ? NIN_W2_ND0 : (NC - K - 1);
+    const bool is_piv = (l == LAM);
+    const double xq = (l > LAM) ? C[Q][K] : 0.0;              // row Q counts as part of x only above the pivot lane
+    double ss = xq * xq;
+#pragma unroll
+    for (int r = Q + 1; r < NR; ++r) ss = fma(C[r][K], C[r][K], ss);
+    double d[ND > 0 ? ND : 1];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int j = K + 1 + i;
+        double a = xq * C[Q][j];
+#pragma unroll
+        for (int r = Q + 1; r < NR; ++r) a = fma(C[r][K], C[r][j], a);
+        d[i] = a;
+    }
+    ss = quad_sum(ss);
+    const double alpha = quad_bcast<LAM>(C[Q][K]);
+    const House h = house_unguarded(alpha, ss);
+    rinvq[Q] = is_piv ? h.rinv : rinvq[Q];
+    const double vpl = is_piv ? h.vp : 0.0;                   // the pivot entry of v, in the pivot lane only
+    const double vq = is_piv ? h.vp : xq;                     // row Q's entry of v in this lane
+#pragma unroll
+    for (int j = K + 1; j < NC; ++j) {
+        double a;
+        if (j - K - 1 < ND) a = fma(vpl, C[Q][j], d[j - K - 1]);
+        else {
+            a = vq * C[Q][j];
+#pragma unroll
+            for (int r = Q + 1; r < NR; ++r) a = fma(C[r][K], C[r][j], a);
+        }
+        const double w = -(h.g * quad_sum(a));
+        C[Q][j] = fma(w, vq, C[Q][j]);                        // the pivot lane's row Q becomes row K of R
+#pragma unroll
+        for (int r = Q + 1; r < NR; ++r) C[r][j] = fma(w, C[r][K], C[r][j]);
+    }
+}
+template <int K, int KEND>
+struct P2LeanLoop {
+    static __device__ __forceinline__ void run(double (&C)[NR][NC], double (&rinvq)[3], int l) {
+        p2_step_lean<K>(C, rinvq, l);
+        P2LeanLoop<K + 1, KEND>::run(C, rinvq, l);
+    }
+};
+template <int KEND>
+struct P2LeanLoop<KEND, KEND> {
+    static __device__ __forceinline__ void run(double (&)[NR][NC], double (&)[3], int) {}
+};
+
+// one column (T) of the block of odd slot S: rows R0A.. of face IA scaled by MA and / or rows R0B.. of face IB by MB; the
+// reflectors of the panel on it; u = z^T R_eo; the seven fill entries to `fill`
+template <bool ZA, bool ZB, bool ZC>
+__device__ __forceinline__ void w2_column(const double (&P)[10][3], const double (&g3)[3], const double (&z)[3], double (&B)[10][1],
+                                          double &u_out, double (&fill)[7]) {
+    apply_panel<1, false, ZA, ZB, ZC>(P, g3, B);
+    u_out = fma(z[2], B[2][0], fma(z[1], B[1][0], z[0] * B[0][0]));
+#pragma unroll
+    for (int r = 0; r < 7; ++r) fill[r] = B[3 + r][0];
+}
+
+// LDS-DMA of one dword per lane (lane i's word lands at row[i]); the compiler does not order LDS reads behind it: every
+// consumer goes through w2_dma_wait()
+__device__ __forceinline__ void w2_dma(const void *gptr, uint32_t *row) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gptr, (__attribute__((address_space(3))) void *)row, 4, 0, 0);
+}
+__device__ __forceinline__ void w2_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// level 0 of group `wg`: list entry and descriptor word (past the end: a clamped, valid entry -- never stored)
+__device__ __forceinline__ void w2_stage_a(const int32_t *nodes, const int32_t *desc, int32_t wg, int32_t count, int nd, int l,
+                                           uint32_t *row_p, uint32_t *row_dsc) {
+    const int32_t idx = wg * NPW + nd;
+    const uint32_t sel = (uint32_t)((idx >= 0 && idx < count) ? idx : count - 1);
+    w2_dma(nodes + sel, row_p);
+    w2_dma(desc + 4 * (size_t)sel + l, row_dsc);
+}
+// level 1: CSR row starts and the node's coordinates (as six dwords)
+__device__ __forceinline__ void w2_stage_b(const GridView &g, uint32_t p, uint32_t *rows_n) {
+    w2_dma(g.esup_ptr + p, rows_n);
+    w2_dma(g.fsup_ptr + p, rows_n + 64);
+    const uint32_t *xw = reinterpret_cast<const uint32_t *>(g.coords) + 6 * (size_t)p;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w2_dma(xw + k, rows_n + 64 * (2 + k));
+}
+// level 2: the lane's two cells, the cells across its three faces, the faces
+__device__ __forceinline__ void w2_stage_c(const GridView &g, uint32_t eb, uint32_t fb, uint32_t dsc, uint32_t *rows_n) {
+    w2_dma(g.esup + eb + (dsc & 7), rows_n + 64 * 8);
+    w2_dma(g.esup + eb + ((dsc >> 3) & 7), rows_n + 64 * 9);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t w = dsc >> (6 + 8 * i);
+        w2_dma(g.esup + eb + ((w >> 4) & 7), rows_n + 64 * (10 + i));
+        w2_dma(g.fsup + fb + (w & 15), rows_n + 64 * (13 + i));
+    }
+}
+
+#ifdef NIN_W2_TRACE
+__device__ unsigned long long nin_w2_trace[4096 * 4];   // per wave: start, end (s_memrealtime, 100 MHz), HW_ID, passes
+#endif
+__global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, const int32_t *__restrict__ nodes,
+                                                                const int32_t *__restrict__ desc, int32_t count,
+                                                                int add_neumann, double *__restrict__ out,
+                                                                double *__restrict__ nws, int32_t *__restrict__ queue) {
+    __shared__ double lds_all[4][W2_WAVE_DOUBLES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane & 3, nd = lane >> 2;
+    double *const L = lds_all[wave] + lane;                   // slot k of this lane: L[64 k]
+    double *const wbuf = lds_all[wave] + W2_SLOTS * 64;
+    // The index levels of the NEXT pass (list entry -> CSR row starts, coordinates -> cell / face ids) come in by LDS-DMA
+    // (global_load_lds_dword: lane i's word lands at row[i]; no register is in flight, nothing the compiler could move or
+    // spill): rows of 64 dwords.  (p, dsc) have rows of their own; the others lie in parking slots 13 .. 20, which are free
+    // from the moment the tile is complete until the next pass parks again -- after it has read them.
+    uint32_t *const row_p = reinterpret_cast<uint32_t *>(lds_all[wave] + W2_SLOTS * 64 + NPW * 8);
+    uint32_t *const row_dsc = row_p + 64;
+    uint32_t *const rows_n = reinterpret_cast<uint32_t *>(lds_all[wave] + 13 * 64);   // 0: eb, 1: fb, 2 .. 7: x_v, 8 .. 15: ids
+
+    const int32_t n_groups = (count + NPW - 1) / NPW;
+    // XCD x walks the x-th contiguous eighth of the node list; its waves pull consecutive 16-node groups off a per-XCD counter.
+    // (Not round-robin: the SIMD issues its OLDER wave first, so the second workgroup of a CU runs at what the first leaves --
+    // 5.85 against 4.0 ms for equal shares, measured.)  The ticket of pass n + 1 is drawn at the top of pass n.
+    int32_t wg_lo, wg_end;
+    int32_t *q;
+    if ((gridDim.x & 7) == 0) {
+        const int32_t xcd = blockIdx.x & 7, per = (n_groups + 7) / 8;
+        wg_lo = xcd * per;
+        wg_end = (xcd + 1) * per < n_groups ? (xcd + 1) * per : n_groups;
+        q = queue + 16 * xcd;   // one counter per 64-byte line
+    } else {
+        wg_lo = 0;
+        wg_end = n_groups;
+        q = queue;
+    }
+    int32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(q, 1);
+    int32_t wg = wg_lo + __builtin_amdgcn_readfirstlane(ticket);
+    if (lane == 0) ticket = atomicAdd(q, 1);
+    int32_t wg_next = wg_lo + __builtin_amdgcn_readfirstlane(ticket);
+    // the first group's index levels, one after the other
+    w2_stage_a(nodes, desc, wg, count, nd, l, row_p, row_dsc);
+    w2_dma_wait();
+    w2_stage_b(g, row_p[lane], rows_n);
+    w2_dma_wait();
+    w2_stage_c(g, rows_n[lane], rows_n[64 + lane], row_dsc[lane], rows_n);
+#ifdef NIN_MF_STAMPS
+    unsigned long long stamps[8];
+    int n_stamp = 0, pass_no = 0;
+#endif
+#ifdef NIN_W2_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned trace_passes = 0;
+#endif
+    while (wg < wg_end) {
+        if (lane == 0) ticket = atomicAdd(q, 1);              // names the group of the pass after the next
+#ifdef NIN_W2_TRACE
+        ++trace_passes;
+#endif
+#ifdef NIN_MF_STAMPS
+        n_stamp = 0;
+#endif
+        NIN_MF_STAMP();                                   // 0: top of the pass
+        // lane-role masks (as multipliers): face i of lane l sits on odd slot i (i < 3 - l) or i + 1
+        const double mA0 = (l != 3) ? 1.0 : 0.0, mA1 = (l < 2) ? 1.0 : 0.0, mA2 = (l == 0) ? 1.0 : 0.0;
+        const double mB1 = (l == 3) ? 1.0 : 0.0, mB2 = (l >= 2) ? 1.0 : 0.0, mB3 = (l != 0) ? 1.0 : 0.0;
+        const bool valid = wg * NPW + nd < count;
+        w2_dma_wait();                                        // (the ids of this pass: requested in the middle of the last one)
+        const uint32_t p = row_p[lane], dsc = row_dsc[lane];
+        const uint32_t eb = rows_n[lane], fb = rows_n[64 + lane];
+        const bool is_neu = (g.flags[p] & 2) != 0;
+        double xv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xv[k] = __hiloint2double((int)rows_n[64 * (3 + 2 * k) + lane], (int)rows_n[64 * (2 + 2 * k) + lane]);
+        uint32_t id[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) id[k] = rows_n[64 * (8 + k) + lane];
+        const uint32_t ce = id[0], co = id[1];
+
+        // ---- the front of E_l: rows 0 = cell row, 1 + 3 i + r = row r of face i; own columns in P ------------
+        double P[10][3], de[3], dod[3], nb0[3][3], sav[3][2][3];
+        {
+            double Ke[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Ke[k] = g.perm[9 * (size_t)ce + k];
+            const double dme = g.diff_mag[ce];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                de[t] = g.centroids[3 * (size_t)ce + t] - xv[t];      // gls.pyx:269-277
+                dod[t] = g.centroids[3 * (size_t)co + t] - xv[t];
+                P[0][t] = de[t];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const uint32_t w = dsc >> (6 + 8 * i);
+                const uint32_t cn = id[2 + i], f = id[5 + i];
+                // B = [K N; T1; tau T2] (gls.pyx:293-321), row = [-B_a | +B_b] (gls.pyx:340-356)
+                const double N0 = (double)g.face_normal[3 * (size_t)f + 0], N1 = (double)g.face_normal[3 * (size_t)f + 1],
+                             N2 = (double)g.face_normal[3 * (size_t)f + 2];
+                const double T0 = xv[0] - g.face_center[3 * (size_t)f + 0], T1 = xv[1] - g.face_center[3 * (size_t)f + 1],
+                             T2 = xv[2] - g.face_center[3 * (size_t)f + 2];
+                const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+                const double dmn = g.diff_mag[cn];
+                double eta = 0.0;
+                eta = dme > eta ? dme : eta;
+                eta = dmn > eta ? dmn : eta;
+                const double un = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
+                const double tj = face_tau(un, eta);
+                const bool side_a = ((w >> 7) & 1) != 0;
+                const double sg = side_a ? -1.0 : 1.0;
+                const double *Kn = g.perm + 9 * (size_t)cn;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    P[1 + 3 * i][t] = sg * (Ke[t * 3 + 0] * N0 + Ke[t * 3 + 1] * N1 + Ke[t * 3 + 2] * N2);
+                    nb0[i][t] = -sg * (Kn[t * 3 + 0] * N0 + Kn[t * 3 + 1] * N1 + Kn[t * 3 + 2] * N2);
+                }
+                sav[i][0][0] = sg * T0; sav[i][0][1] = sg * T1; sav[i][0][2] = sg * T2;
+                sav[i][1][0] = sg * (tj * U0); sav[i][1][1] = sg * (tj * U1); sav[i][1][2] = sg * (tj * U2);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { P[2 + 3 * i][t] = sav[i][0][t]; P[3 + 3 * i][t] = sav[i][1][t]; }
+            }
+        }
+        NIN_MF_STAMP();                                   // 1: geometry in, face rows done
+        w2_stage_a(nodes, desc, wg_next, count, nd, l, row_p, row_dsc);   // next pass: list entry and descriptor
+        double C[NR][NC];
+        double u[12], se;
+        {
+            double g3[3], z[3];
+            front_panel(P, de, g3, z);
+            pin(z[0]); pin(z[1]); pin(z[2]);
+            {
+                double Bc[10][1];
+                Bc[0][0] = 1.0;                               // c = e_0 on entry: only the cell row carries a 1
+                apply_panel<1, true, false, false, false>(P, g3, Bc);
+                se = fma(z[2], Bc[2][0], fma(z[1], Bc[1][0], z[0] * Bc[0][0]));
+                pin(se);
+#pragma unroll
+                for (int r = 0; r < 7; ++r) L[64 * r] = Bc[3 + r][0];                       // slots 0 .. 6: column c
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {                                                    // odd slot 0 <- face 0 (lanes 0 .. 2)
+                double B[10][1], fill[7];
+                B[1][0] = mA0 * nb0[0][t]; B[2][0] = -(mA0 * sav[0][0][t]); B[3][0] = -(mA0 * sav[0][1][t]);
+                w2_column<true, false, false>(P, g3, z, B, u[t], fill);
+                pin(u[t]);
+#pragma unroll
+                for (int r = 0; r < 7; ++r) L[64 * (7 + 7 * t + r)] = fill[r];               // slots 7 .. 27
+                NIN_W2_COLUMN_FENCE();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {                                                    // odd slot 1 <- face 0 (lane 3) or face 1 (lanes 0, 1)
+                double B[10][1], fill[7];
+                B[1][0] = mB1 * nb0[0][t]; B[2][0] = -(mB1 * sav[0][0][t]); B[3][0] = -(mB1 * sav[0][1][t]);
+                B[4][0] = mA1 * nb0[1][t]; B[5][0] = -(mA1 * sav[1][0][t]); B[6][0] = -(mA1 * sav[1][1][t]);
+                w2_column<true, true, false>(P, g3, z, B, u[3 + t], fill);
+                pin(u[3 + t]);
+                if (t == 0) {
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) L[64 * (28 + r)] = fill[r];                  // slots 28 .. 34
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) C[r][3 + t] = fill[r];
+                }
+                NIN_W2_COLUMN_FENCE();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {                                                    // odd slot 2 <- face 1 (lanes 2, 3) or face 2 (lane 0)
+                double B[10][1], fill[7];
+                B[4][0] = mB2 * nb0[1][t]; B[5][0] = -(mB2 * sav[1][0][t]); B[6][0] = -(mB2 * sav[1][1][t]);
+                B[7][0] = mA2 * nb0[2][t]; B[8][0] = -(mA2 * sav[2][0][t]); B[9][0] = -(mA2 * sav[2][1][t]);
+                w2_column<false, true, true>(P, g3, z, B, u[6 + t], fill);
+                pin(u[6 + t]);
+#pragma unroll
+                for (int r = 0; r < 7; ++r) C[r][6 + t] = fill[r];
+                NIN_W2_COLUMN_FENCE();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {                                                    // odd slot 3 <- face 2 (lanes 1 .. 3)
+                double B[10][1], fill[7];
+                B[7][0] = mB3 * nb0[2][t]; B[8][0] = -(mB3 * sav[2][0][t]); B[9][0] = -(mB3 * sav[2][1][t]);
+                w2_column<false, false, true>(P, g3, z, B, u[9 + t], fill);
+                pin(u[9 + t]);
+#pragma unroll
+                for (int r = 0; r < 7; ++r) C[r][9 + t] = fill[r];
+                NIN_W2_COLUMN_FENCE();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        NIN_MF_STAMP();                                   // 2: phase 1 done
+        // the fill entries that waited in LDS come back; u and s take their place
+#pragma unroll
+        for (int r = 0; r < 7; ++r) C[r][12] = L[64 * r];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) C[r][t] = L[64 * (7 + 7 * t + r)];
+        }
+#pragma unroll
+        for (int r = 0; r < 7; ++r) C[r][3] = L[64 * (28 + r)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) L[64 * j] = u[j];
+        L[64 * 12] = se;
+        // row 7: the cell row of O_l, (x_K - x_v) on the columns of odd slot l, c = 1
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) C[7][3 * s + t] = (l == s) ? dod[t] : 0.0;
+        }
+        C[7][12] = 1.0;
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- phase 2: 32 x 12 over the quad ------------------------------------------------------------------
+        double rinvq[3] = {0.0, 0.0, 0.0};
+        NIN_MF_STAMP();                                   // 3: tile complete
+        w2_dma_wait();
+        w2_stage_b(g, row_p[lane], rows_n);               // next pass: CSR row starts, node coordinates
+        __builtin_amdgcn_sched_barrier(0);
+        P2LeanLoop<0, 6>::run(C, rinvq, l);
+        NIN_MF_STAMP();                                   // 4: phase 2, steps 0-5
+        __builtin_amdgcn_sched_barrier(0);
+        w2_dma_wait();
+        w2_stage_c(g, rows_n[lane], rows_n[64 + lane], row_dsc[lane], rows_n);   // next pass: cell and face ids
+        __builtin_amdgcn_sched_barrier(0);
+        P2LeanLoop<6, 12>::run(C, rinvq, l);
+        NIN_MF_STAMP();                                   // 5: phase 2 done
+        double y[12], t3[3] = {C[0][12], C[1][12], C[2][12]};
+        BackLoop<11>::run(C, rinvq, t3, y, l);
+        NIN_MF_STAMP();                                   // 6: back-substitution done
+        double tail = 0.0;
+#pragma unroll
+        for (int r = 3; r < NR; ++r) tail = fma(C[r][12], C[r][12], tail);
+        const double rr = quad_sum(tail);                        // r . r = |(Q^T c)(24:44)|^2
+
+        // ---- residuals on the two cell rows of this lane, weights ----------------------------------------------
+        double re = 1.0 - L[64 * 12];                            // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_odd
+#pragma unroll
+        for (int j = 0; j < 12; ++j) re = fma(L[64 * j], y[j], re);
+        double dots[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dots[s] = fma(dod[2], y[3 * s + 2], fma(dod[1], y[3 * s + 1], dod[0] * y[3 * s]));
+        const double dsel = (l == 0) ? dots[0] : (l == 1) ? dots[1] : (l == 2) ? dots[2] : dots[3];
+        const double ro = 1.0 - dsel;
+        const double rri = fast_rcp(rr);
+        double we = re * rri, wo = ro * rri;
+        const bool ok = rr > 0.0;                                // (as above: the zero row for a rank-deficient system)
+        we = (ok && __builtin_isfinite(we)) ? we : 0.0;
+        wo = (ok && __builtin_isfinite(wo)) ? wo : 0.0;
+
+        wbuf[nd * 8 + (dsc & 7)] = we;
+        wbuf[nd * 8 + ((dsc >> 3) & 7)] = wo;
+        wave_lds_sync();
+        const double nwv = is_neu ? wbuf[nd * 8 + 7] : 0.0;      // gls.pyx:470-472
+        const double addv = add_neumann ? nwv : 0.0;
+        const double o0 = wbuf[nd * 8 + 2 * l] + addv, o1 = wbuf[nd * 8 + 2 * l + 1] + addv;
+        if (valid) {
+            out[eb + 2 * l] = o0;
+            out[eb + 2 * l + 1] = o1;
+            if (l == 0) nws[p] = nwv;
+        }
+        wave_lds_sync();
+        NIN_MF_STAMP();                                   // 7: weights stored
+#ifdef NIN_MF_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0 && ++pass_no == NIN_MF_STAMP_PASS)
+            for (int i = 0; i < 8; ++i) nws[nodes[i]] = (double)(stamps[i] - stamps[0]);   // (diagnostic build: clobbers neumann_ws of the first 8 listed nodes)
+#endif
+        wg = wg_next;
+        wg_next = wg_lo + __builtin_amdgcn_readfirstlane(ticket);
+    }
+    w2_dma_wait();   // nothing may still be on its way into this workgroup's LDS when the wave ends
+#ifdef NIN_W2_TRACE
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long *t = nin_w2_trace + 4 * ((size_t)blockIdx.x * 4 + wave);
+        t[0] = trace_t0;
+        t[1] = __builtin_amdgcn_s_memrealtime();
+        t[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+        t[3] = trace_passes;
+    }
+#endif
 }
 
 __global__ void k_hex8_desc(GridView g, const int32_t *__restrict__ nodes, int32_t count, int32_t *__restrict__ desc) {
@@ -493,6 +908,34 @@ int launch_hex8_desc(const GridView &g, const int32_t *nodes, int32_t count, int
 int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
                       double *out, double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
+    if (getenv("NIN_HEX8_ONE_WAVE") == nullptr) {   // (A/B switch: the one-wave-per-SIMD kernel of round 2)
+        int64_t blocks = ((int64_t)count + 4 * NPW - 1) / (4 * NPW);
+        const char *cap_env = getenv("NIN_W2_BLOCKS");   // (experiments)
+        const int64_t cap2 = cap_env ? atoll(cap_env) : 512;
+        if (blocks > cap2) blocks = cap2;            // two 4-wave workgroups per CU are resident (256 registers, 74 KB of LDS each)
+        if (blocks > 8) blocks &= ~(int64_t)7;
+        if (getenv("NIN_DEBUG_OCCUPANCY") != nullptr) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nin_gls_hex8w2_kernel, 256, 0);
+            fprintf(stderr, "nin_gls_hex8w2_kernel: %d workgroups per CU, %lld launched\n", nb, (long long)blocks);
+        }
+        hipLaunchKernelGGL(nin_gls_hex8w2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count, add_neumann, out, nws, queue);
+#ifdef NIN_W2_TRACE
+        if (getenv("NIN_W2_TRACE_FILE") != nullptr) {
+            static int calls = 0;
+            if (++calls == 6) {
+                (void)hipStreamSynchronize(stream);
+                static unsigned long long host[4096 * 4];
+                (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(nin_w2_trace), sizeof(host));
+                FILE *f = fopen(getenv("NIN_W2_TRACE_FILE"), "w");
+                for (int64_t b = 0; b < blocks * 4 && b < 4096; ++b)
+                    fprintf(f, "%lld %llu %llu %llx %llu\n", (long long)b, host[4 * b], host[4 * b + 1], host[4 * b + 2], host[4 * b + 3]);
+                fclose(f);
+            }
+        }
+#endif
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     int64_t blocks = ((int64_t)count + 4 * NPW - 1) / (4 * NPW);
     const int64_t cap = 256;   // 512 registers per lane: one 4-wave workgroup per CU is resident; persistent, blockIdx % 8 = XCD
     if (blocks > cap) blocks = cap;
@@ -502,6 +945,6 @@ int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *de
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-const char *kernel_name_gls_hex8mf() { return "nin_gls_hex8mf_kernel"; }
+const char *kernel_name_gls_hex8mf() { return getenv("NIN_HEX8_ONE_WAVE") == nullptr ? "nin_gls_hex8w2_kernel" : "nin_gls_hex8mf_kernel"; }
 
 }  // namespace nin
