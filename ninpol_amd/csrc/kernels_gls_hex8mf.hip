@@ -666,9 +666,6 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
         n_stamp = 0;
 #endif
         NIN_MF_STAMP();                                   // 0: top of the pass
-        // lane-role masks (as multipliers): face i of lane l sits on odd slot i (i < 3 - l) or i + 1
-        const double mA0 = (l != 3) ? 1.0 : 0.0, mA1 = (l < 2) ? 1.0 : 0.0, mA2 = (l == 0) ? 1.0 : 0.0;
-        const double mB1 = (l == 3) ? 1.0 : 0.0, mB2 = (l >= 2) ? 1.0 : 0.0, mB3 = (l != 0) ? 1.0 : 0.0;
         const bool valid = wg * NPW + nd < count;
         w2_dma_wait();                                        // (the ids of this pass: requested in the middle of the last one)
         const uint32_t p = row_p[lane], dsc = row_dsc[lane];
@@ -728,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
         NIN_MF_STAMP();                                   // 1: geometry in, face rows done
         w2_stage_a(nodes, desc, wg_next, count, nd, l, row_p, row_dsc);   // next pass: list entry and descriptor
         double C[NR][NC];
-        double u[12], se;
+        double u[9], se, F1[7][2], F2[7][3];                  // u = z^T R_eo by face; fill entries of faces 1 and 2 (face 0: LDS)
         {
             double g3[3], z[3];
             front_panel(P, de, g3, z);
@@ -743,73 +740,73 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
                 for (int r = 0; r < 7; ++r) L[64 * r] = Bc[3 + r][0];                       // slots 0 .. 6: column c
             }
             __builtin_amdgcn_sched_barrier(0);
+            // The blocks in FACE order: face i of lane l belongs to odd slot i (i < 3 - l) or i + 1, and the slot a lane has
+            // no face on (3 - l) is zero -- so every lane runs three one-face blocks, no role masks, no block of zeros, and
+            // the fill entries F0, F1, F2 find their slots when the tile is put together (selects by lane role).
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {                                                    // odd slot 0 <- face 0 (lanes 0 .. 2)
+            for (int t = 0; t < 3; ++t) {                                                    // face 0: rows 1 .. 3
                 double B[10][1], fill[7];
-                B[1][0] = mA0 * nb0[0][t]; B[2][0] = -(mA0 * sav[0][0][t]); B[3][0] = -(mA0 * sav[0][1][t]);
+                B[1][0] = nb0[0][t]; B[2][0] = -sav[0][0][t]; B[3][0] = -sav[0][1][t];
                 w2_column<true, false, false>(P, g3, z, B, u[t], fill);
                 pin(u[t]);
 #pragma unroll
-                for (int r = 0; r < 7; ++r) L[64 * (7 + 7 * t + r)] = fill[r];               // slots 7 .. 27
+                for (int r = 0; r < 7; ++r) L[64 * (7 + 7 * t + r)] = fill[r];               // slots 7 .. 27: F0
                 NIN_W2_COLUMN_FENCE();
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {                                                    // odd slot 1 <- face 0 (lane 3) or face 1 (lanes 0, 1)
+            for (int t = 0; t < 3; ++t) {                                                    // face 1: rows 4 .. 6
                 double B[10][1], fill[7];
-                B[1][0] = mB1 * nb0[0][t]; B[2][0] = -(mB1 * sav[0][0][t]); B[3][0] = -(mB1 * sav[0][1][t]);
-                B[4][0] = mA1 * nb0[1][t]; B[5][0] = -(mA1 * sav[1][0][t]); B[6][0] = -(mA1 * sav[1][1][t]);
-                w2_column<true, true, false>(P, g3, z, B, u[3 + t], fill);
+                B[4][0] = nb0[1][t]; B[5][0] = -sav[1][0][t]; B[6][0] = -sav[1][1][t];
+                w2_column<false, true, false>(P, g3, z, B, u[3 + t], fill);
                 pin(u[3 + t]);
                 if (t == 0) {
 #pragma unroll
-                    for (int r = 0; r < 7; ++r) L[64 * (28 + r)] = fill[r];                  // slots 28 .. 34
+                    for (int r = 0; r < 7; ++r) L[64 * (28 + r)] = fill[r];                  // slots 28 .. 34: F1, first column
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 7; ++r) C[r][3 + t] = fill[r];
+                    for (int r = 0; r < 7; ++r) F1[r][t - 1] = fill[r];
                 }
                 NIN_W2_COLUMN_FENCE();
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {                                                    // odd slot 2 <- face 1 (lanes 2, 3) or face 2 (lane 0)
+            for (int t = 0; t < 3; ++t) {                                                    // face 2: rows 7 .. 9
                 double B[10][1], fill[7];
-                B[4][0] = mB2 * nb0[1][t]; B[5][0] = -(mB2 * sav[1][0][t]); B[6][0] = -(mB2 * sav[1][1][t]);
-                B[7][0] = mA2 * nb0[2][t]; B[8][0] = -(mA2 * sav[2][0][t]); B[9][0] = -(mA2 * sav[2][1][t]);
-                w2_column<false, true, true>(P, g3, z, B, u[6 + t], fill);
+                B[7][0] = nb0[2][t]; B[8][0] = -sav[2][0][t]; B[9][0] = -sav[2][1][t];
+                w2_column<false, false, true>(P, g3, z, B, u[6 + t], fill);
                 pin(u[6 + t]);
 #pragma unroll
-                for (int r = 0; r < 7; ++r) C[r][6 + t] = fill[r];
-                NIN_W2_COLUMN_FENCE();
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {                                                    // odd slot 3 <- face 2 (lanes 1 .. 3)
-                double B[10][1], fill[7];
-                B[7][0] = mB3 * nb0[2][t]; B[8][0] = -(mB3 * sav[2][0][t]); B[9][0] = -(mB3 * sav[2][1][t]);
-                w2_column<false, false, true>(P, g3, z, B, u[9 + t], fill);
-                pin(u[9 + t]);
-#pragma unroll
-                for (int r = 0; r < 7; ++r) C[r][9 + t] = fill[r];
+                for (int r = 0; r < 7; ++r) F2[r][t] = fill[r];
                 NIN_W2_COLUMN_FENCE();
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         NIN_MF_STAMP();                                   // 2: phase 1 done
-        // the fill entries that waited in LDS come back; u and s take their place
+        // ---- the tile: odd slot 0 = F0 (lanes 0 .. 2); slot 1 = F1 (lanes 0, 1) or F0 (lane 3); slot 2 = F2 (lane 0) or F1
+        //      (lanes 2, 3); slot 3 = F2 (lanes 1 .. 3); the slot a lane has no face on is zero.  The entries that waited in LDS
+        //      come back; u and s take their place ------------------------------------------------------------------------------
+        {
+            const bool lt3 = l < 3, lt2 = l < 2, eq0 = l == 0, ge2 = l >= 2, ge1 = l >= 1, eq3 = l == 3;
 #pragma unroll
-        for (int r = 0; r < 7; ++r) C[r][12] = L[64 * r];
+            for (int t = 0; t < 3; ++t) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+                for (int r = 0; r < 7; ++r) {
+                    const double f1 = (t == 0) ? L[64 * (28 + r)] : F1[r][t == 0 ? 0 : t - 1];
+                    const double f0 = L[64 * (7 + 7 * t + r)];
+                    C[r][6 + t] = eq0 ? F2[r][t] : (ge2 ? f1 : 0.0);
+                    C[r][9 + t] = ge1 ? F2[r][t] : 0.0;
+                    C[r][3 + t] = lt2 ? f1 : (eq3 ? f0 : 0.0);
+                    C[r][t] = lt3 ? f0 : 0.0;
+                }
+            }
 #pragma unroll
-            for (int r = 0; r < 7; ++r) C[r][t] = L[64 * (7 + 7 * t + r)];
+            for (int r = 0; r < 7; ++r) C[r][12] = L[64 * r];
         }
-#pragma unroll
-        for (int r = 0; r < 7; ++r) C[r][3] = L[64 * (28 + r)];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 12; ++j) L[64 * j] = u[j];
-        L[64 * 12] = se;
+        for (int j = 0; j < 9; ++j) L[64 * j] = u[j];
+        L[64 * 9] = se;
         // row 7: the cell row of O_l, (x_K - x_v) on the columns of odd slot l, c = 1
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -842,9 +839,13 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
         const double rr = quad_sum(tail);                        // r . r = |(Q^T c)(24:44)|^2
 
         // ---- residuals on the two cell rows of this lane, weights ----------------------------------------------
-        double re = 1.0 - L[64 * 12];                            // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_odd
+        double re = 1.0 - L[64 * 9];                             // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_odd
 #pragma unroll
-        for (int j = 0; j < 12; ++j) re = fma(L[64 * j], y[j], re);
+        for (int i = 0; i < 3; ++i) {                            // face i sits on odd slot i (i < 3 - l) or i + 1
+            const bool low = i < 3 - l;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) re = fma(L[64 * (3 * i + t)], low ? y[3 * i + t] : y[3 * i + 3 + t], re);
+        }
         double dots[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) dots[s] = fma(dod[2], y[3 * s + 2], fma(dod[1], y[3 * s + 1], dod[0] * y[3 * s]));
