@@ -65,7 +65,7 @@ __device__ __forceinline__ House house_unguarded(double alpha, double ss) {
     h.beta = -copysign(sq, alpha);
     h.vp = alpha - h.beta;
     h.g = NIN_HOUSE_RCP(fma(fabs(alpha), sq, S));
-    h.rinv = -(h.g * h.vp);
+    h.rinv = -copysign(rs, alpha);                          // 1 / beta
     return h;
 }
 __device__ __forceinline__ House house(double alpha, double ss) {
@@ -87,7 +87,9 @@ __device__ __forceinline__ House house(double alpha, double ss) {
 // |r| <= 0.347, Taylor to r^14 (4e-18) and ldexp.  Against numpy's pow over u in [1e-6, 1e2], eta in (0, 1]: max
 // relative error 1.8e-15, mean 1.6e-16 -- five orders below the 1e-10 weight tolerance.  Kept out of line:
 // inlined, the series coefficients are hoisted out of the node loop and stay live across the whole QR.
-__device__ __attribute__((noinline)) static double face_tau(double un, double eta) {
+// SQUARED = true: the argument is |T_sj2|^2 and the result the same tau = (un2)^(-eta / 2) -- the caller skips the square root
+template <bool SQUARED>
+__device__ __attribute__((noinline)) static double face_tau_t(double un, double eta) {
     if (eta == 0.0) return 1.0;
     constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     double m = __builtin_amdgcn_frexp_mant(un);            // [0.5, 1)
@@ -107,7 +109,7 @@ __device__ __attribute__((noinline)) static double face_tau(double un, double et
     p = fma(p, z, 1.0 / 13.0); p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0);  p = fma(p, z, 1.0 / 7.0);
     p = fma(p, z, 1.0 / 5.0);  p = fma(p, z, 1.0 / 3.0);  p = fma(p, z, 1.0);
     const double lg = fma(ef, LN2_HI, fma(ef, LN2_LO, 2.0 * sn * p));   // log(un)
-    const double y = -eta * lg;
+    const double y = (SQUARED ? -0.5 * eta : -eta) * lg;
     const double k = rint(y * 1.44269504088896340736);
     const double rr = fma(-k, LN2_LO, fma(-k, LN2_HI, y));
     double q = 1.0 / 87178291200.0;                        // 1 / 14!
@@ -118,6 +120,8 @@ __device__ __attribute__((noinline)) static double face_tau(double un, double et
     q = fma(q, rr, 1.0);                q = fma(q, rr, 1.0);
     return __builtin_amdgcn_ldexp(q, (int)k);
 }
+__device__ __forceinline__ double face_tau(double un, double eta) { return face_tau_t<false>(un, eta); }
+__device__ __forceinline__ double face_tau_sq(double un2, double eta) { return face_tau_t<true>(un2, eta); }
 
 // The panel of a front: three Householder steps on the front cell's own columns (10 rows: the cell row and the 3 x 3
 // rows of its faces).  v_k stays in P[k..9][k] (pivot entries included), R's off-diagonal entries in P[0][1], P[0][2],

@@ -706,8 +706,7 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
                 double eta = 0.0;
                 eta = dme > eta ? dme : eta;
                 eta = dmn > eta ? dmn : eta;
-                const double un = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
-                const double tj = face_tau(un, eta);
+                const double tj = face_tau_sq(U0 * U0 + U1 * U1 + U2 * U2, eta);   // |T_sj2|^(-eta) without the square root
                 const bool side_a = ((w >> 7) & 1) != 0;
                 const double sg = side_a ? -1.0 : 1.0;
                 const double *Kn = g.perm + 9 * (size_t)cn;
