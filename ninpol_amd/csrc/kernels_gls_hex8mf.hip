@@ -504,41 +504,24 @@ constexpr int W2_WAVE_DOUBLES = W2_SLOTS * 64 + NPW * 8 + 64;  // + the weights'
 template <int K>
 __device__ __forceinline__ void p2_step_lean(double (&C)[NR][NC], double (&rinvq)[3], int l) {
     constexpr int Q = K / 4, LAM = K % 4;
-    // partial dots that are formed BEFORE the step's scalars (they do not need them, and fill that chain's latency): as many
-    // as the registers allow -- at step 0 the tile is complete and only a few fit, from step 1 on the retired column pays for all
-#ifndef NIN_W2_ND0
-#define NIN_W2_ND0 5
-#endif
-    constexpr int ND = (K == 0) ? NIN_W2_ND0 : (NC - K - 1);
+    // (each column's dot is formed where it is used: ahead of the step's scalars -- the one-wave kernel's way of filling that
+    //  chain's latency -- it costs one more FMA per column for the pivot lane's entry, and the other wave fills the latency
+    //  here: 5.05 -> 4.92 ms, measured)
     const bool is_piv = (l == LAM);
     const double xq = (l > LAM) ? C[Q][K] : 0.0;              // row Q counts as part of x only above the pivot lane
     double ss = xq * xq;
 #pragma unroll
     for (int r = Q + 1; r < NR; ++r) ss = fma(C[r][K], C[r][K], ss);
-    double d[ND > 0 ? ND : 1];
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-        const int j = K + 1 + i;
-        double a = xq * C[Q][j];
-#pragma unroll
-        for (int r = Q + 1; r < NR; ++r) a = fma(C[r][K], C[r][j], a);
-        d[i] = a;
-    }
     ss = quad_sum(ss);
     const double alpha = quad_bcast<LAM>(C[Q][K]);
     const House h = house_unguarded(alpha, ss);
     rinvq[Q] = is_piv ? h.rinv : rinvq[Q];
-    const double vpl = is_piv ? h.vp : 0.0;                   // the pivot entry of v, in the pivot lane only
     const double vq = is_piv ? h.vp : xq;                     // row Q's entry of v in this lane
 #pragma unroll
     for (int j = K + 1; j < NC; ++j) {
-        double a;
-        if (j - K - 1 < ND) a = fma(vpl, C[Q][j], d[j - K - 1]);
-        else {
-            a = vq * C[Q][j];
+        double a = vq * C[Q][j];
 #pragma unroll
-            for (int r = Q + 1; r < NR; ++r) a = fma(C[r][K], C[r][j], a);
-        }
+        for (int r = Q + 1; r < NR; ++r) a = fma(C[r][K], C[r][j], a);
         const double w = -(h.g * quad_sum(a));
         C[Q][j] = fma(w, vq, C[Q][j]);                        // the pivot lane's row Q becomes row K of R
 #pragma unroll
@@ -557,15 +540,39 @@ struct P2LeanLoop<KEND, KEND> {
     static __device__ __forceinline__ void run(double (&)[NR][NC], double (&)[3], int) {}
 };
 
-// one column (T) of the block of odd slot S: rows R0A.. of face IA scaled by MA and / or rows R0B.. of face IB by MB; the
-// reflectors of the panel on it; u = z^T R_eo; the seven fill entries to `fill`
-template <bool ZA, bool ZB, bool ZC>
-__device__ __forceinline__ void w2_column(const double (&P)[10][3], const double (&g3)[3], const double (&z)[3], double (&B)[10][1],
-                                          double &u_out, double (&fill)[7]) {
-    apply_panel<1, false, ZA, ZB, ZC>(P, g3, B);
-    u_out = fma(z[2], B[2][0], fma(z[1], B[1][0], z[0] * B[0][0]));
+// The three reflectors of a front's panel on a column that enters with ONE face's three entries (rows R0 .. R0 + 2: b[0 .. 2])
+// and zeros elsewhere.  With the reflectors' mutual products cc = (v1 . v0, v2 . v0, v2 . v1) known (once per node), the dots
+// with the filled column need the face's rows only -- H2 H1 H0 b = b + w0 v0 + w1 v1 + w2 v2,
+//   w0 = -g0 (v0 . b),  w1 = -g1 (v1 . b + w0 v1 . v0),  w2 = -g2 (v2 . b + w0 v2 . v0 + w1 v2 . v1)
+// -- 45 operations a column against 54 for the three reflectors one after the other.  v_k = P[k .. 9][k] (pivot entries
+// included).  Out: u = z^T (rows 0 .. 2), the seven fill entries (rows 3 .. 9).  R0 < 0: the column c = e_0.
+template <int R0>
+__device__ __forceinline__ void w2_column(const double (&P)[10][3], const double (&g3)[3], const double (&cc)[3], const double (&z)[3],
+                                          const double (&b)[3], double &u_out, double (&fill)[7]) {
+    double w0, w1, w2;
+    if (R0 < 0) {
+        w0 = -(g3[0] * P[0][0]);
+        w1 = -(g3[1] * (w0 * cc[0]));
+        w2 = -(g3[2] * fma(w1, cc[2], w0 * cc[1]));
+    } else {
+        w0 = -(g3[0] * fma(P[R0 + 2][0], b[2], fma(P[R0 + 1][0], b[1], P[R0][0] * b[0])));
+        w1 = -(g3[1] * fma(w0, cc[0], fma(P[R0 + 2][1], b[2], fma(P[R0 + 1][1], b[1], P[R0][1] * b[0]))));
+        const double d2 = (R0 >= 2) ? fma(P[R0 + 2][2], b[2], fma(P[R0 + 1][2], b[1], P[R0 < 0 ? 0 : R0][2] * b[0]))
+                                    : fma(P[R0 + 2][2], b[2], P[R0 + 1][2] * b[1]);     // (R0 = 1: row 1 lies above v2)
+        w2 = -(g3[2] * fma(w1, cc[2], fma(w0, cc[1], d2)));
+    }
+    double B[10];
 #pragma unroll
-    for (int r = 0; r < 7; ++r) fill[r] = B[3 + r][0];
+    for (int r = 0; r < 10; ++r) {
+        const bool own = R0 >= 0 && r >= R0 && r < R0 + 3;
+        double v = own ? fma(w0, P[r][0], b[own ? r - R0 : 0]) : (R0 < 0 && r == 0) ? fma(w0, P[0][0], 1.0) : w0 * P[r][0];
+        if (r >= 1) v = fma(w1, P[r][1], v);
+        if (r >= 2) v = fma(w2, P[r][2], v);
+        B[r] = v;
+    }
+    u_out = fma(z[2], B[2], fma(z[1], B[1], z[0] * B[0]));
+#pragma unroll
+    for (int r = 0; r < 7; ++r) fill[r] = B[3 + r];
 }
 
 // LDS-DMA of one dword per lane (lane i's word lands at row[i]); the compiler does not order LDS reads behind it: every
@@ -729,14 +736,22 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
             double g3[3], z[3];
             front_panel(P, de, g3, z);
             pin(z[0]); pin(z[1]); pin(z[2]);
+            // the reflectors' mutual products (w2_column)
+            double cc[3];
+            cc[0] = P[1][1] * P[1][0];
+            cc[1] = P[2][2] * P[2][0];
+            cc[2] = P[2][2] * P[2][1];
+#pragma unroll
+            for (int r = 2; r < 10; ++r) cc[0] = fma(P[r][1], P[r][0], cc[0]);
+#pragma unroll
+            for (int r = 3; r < 10; ++r) { cc[1] = fma(P[r][2], P[r][0], cc[1]); cc[2] = fma(P[r][2], P[r][1], cc[2]); }
             {
-                double Bc[10][1];
-                Bc[0][0] = 1.0;                               // c = e_0 on entry: only the cell row carries a 1
-                apply_panel<1, true, false, false, false>(P, g3, Bc);
-                se = fma(z[2], Bc[2][0], fma(z[1], Bc[1][0], z[0] * Bc[0][0]));
+                const double none[3] = {0.0, 0.0, 0.0};
+                double fill[7];
+                w2_column<-1>(P, g3, cc, z, none, se, fill);   // c = e_0 on entry: only the cell row carries a 1
                 pin(se);
 #pragma unroll
-                for (int r = 0; r < 7; ++r) L[64 * r] = Bc[3 + r][0];                       // slots 0 .. 6: column c
+                for (int r = 0; r < 7; ++r) L[64 * r] = fill[r];                            // slots 0 .. 6: column c
             }
             __builtin_amdgcn_sched_barrier(0);
             // The blocks in FACE order: face i of lane l belongs to odd slot i (i < 3 - l) or i + 1, and the slot a lane has
@@ -744,9 +759,9 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
             // the fill entries F0, F1, F2 find their slots when the tile is put together (selects by lane role).
 #pragma unroll
             for (int t = 0; t < 3; ++t) {                                                    // face 0: rows 1 .. 3
-                double B[10][1], fill[7];
-                B[1][0] = nb0[0][t]; B[2][0] = -sav[0][0][t]; B[3][0] = -sav[0][1][t];
-                w2_column<true, false, false>(P, g3, z, B, u[t], fill);
+                const double b[3] = {nb0[0][t], -sav[0][0][t], -sav[0][1][t]};
+                double fill[7];
+                w2_column<1>(P, g3, cc, z, b, u[t], fill);
                 pin(u[t]);
 #pragma unroll
                 for (int r = 0; r < 7; ++r) L[64 * (7 + 7 * t + r)] = fill[r];               // slots 7 .. 27: F0
@@ -755,9 +770,9 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {                                                    // face 1: rows 4 .. 6
-                double B[10][1], fill[7];
-                B[4][0] = nb0[1][t]; B[5][0] = -sav[1][0][t]; B[6][0] = -sav[1][1][t];
-                w2_column<false, true, false>(P, g3, z, B, u[3 + t], fill);
+                const double b[3] = {nb0[1][t], -sav[1][0][t], -sav[1][1][t]};
+                double fill[7];
+                w2_column<4>(P, g3, cc, z, b, u[3 + t], fill);
                 pin(u[3 + t]);
                 if (t == 0) {
 #pragma unroll
@@ -771,9 +786,9 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {                                                    // face 2: rows 7 .. 9
-                double B[10][1], fill[7];
-                B[7][0] = nb0[2][t]; B[8][0] = -sav[2][0][t]; B[9][0] = -sav[2][1][t];
-                w2_column<false, false, true>(P, g3, z, B, u[6 + t], fill);
+                const double b[3] = {nb0[2][t], -sav[2][0][t], -sav[2][1][t]};
+                double fill[7];
+                w2_column<7>(P, g3, cc, z, b, u[6 + t], fill);
                 pin(u[6 + t]);
 #pragma unroll
                 for (int r = 0; r < 7; ++r) F2[r][t] = fill[r];
