@@ -48,8 +48,9 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/
 FP64_PEAK_TFLOPS = 78.6     # vector FP64
 REF_FLOPS_PER_NODE_HEX = 74.8e3   # dgels 44 x 25 x 8 per interior hexahedron node
 # FP64 operations the multifrontal kernel EXECUTES per interior hexahedron node (fma = 2, mul / add = 1, the 4 lanes
-# of a node summed), counted on the kernel's ISA by tools/count_fp64.py (profiles/r02/hex8mf_isa_mix.txt)
-EXEC_FLOPS_PER_NODE_HEX = 20.5e3
+# of a node summed), counted on the kernel's ISA by tools/count_fp64.py (profiles/r03/hex8w2_isa_mix.txt; round 2's
+# one-wave kernel: 20.5e3, profiles/r02/hex8mf_isa_mix.txt)
+EXEC_FLOPS_PER_NODE_HEX = 16.7e3
 # ALGORITHMIC FP64 flops per node of the multifrontal formulation -- useful arithmetic only, no role masks, no redundant
 # panel work (tools/count_algorithmic_flops.py, profiles/r03/algorithmic_flops.txt) -- by node kind: (fronts, dense cells)
 ALG_FLOPS = {"cube": 15869.0, "kuhn": 250357.0, "wedge": 40075.0}
@@ -412,7 +413,7 @@ def main():
                             "executed_tflops": roof["executed_tflops"], "executed_frac": roof["executed_frac"],
                             "note": "ref_equiv prices the node rate at the reference's dense dgels 44x25x8 = 74.8 kflop/node "
                                     "(SURVEY 8d); the multifrontal formulation needs 15.9 kflop/node (algorithmic) and the kernel "
-                                    "executes 20.5 (role masks, redundant panel work), so ref_equiv may pass 1"}
+                                    "executes 16.7 (the reflector scalars in all four lanes of a node, the quad sums), so ref_equiv may pass 1"}
         if world == 1 and not args.no_extras:
             # context: the two HBM-bound methods on the same grid, and end-to-end interpolate()
             for meth in ("idw", "ls"):
