@@ -144,6 +144,83 @@ bool lookup_array(nin_grid *g, const std::string &name, ArrayRef *r) {
     return false;
 }
 
+
+// ---- locality order of a kernel's node list --------------------------------------------------------------------------------
+// A list in node order walks the mesh the way its nodes are numbered (a structured mesh: along x), and a node shares its cells
+// and faces with neighbours that are a whole row or plane of the numbering away: with 2 x 256 groups of a kernel in flight per
+// XCD the data comes in again for every plane (FETCH_SIZE 3.58 GiB per launch at 216^3 against 2.6 with half as many waves).
+// So the list is put in Morton order of the node coordinates (10 bits an axis over the mesh's bounding cube) -- inside each piece
+// of interpolate()'s pipeline, whose pieces stay sub-ranges of the list.
+// Runs of 16 consecutive entries (one pass of a 16-nodes-per-wavefront kernel) move as one: inside a run the rows of the CSR
+// tables and of the output stay next to each other -- single nodes in Morton order cost more in uncoalesced requests than
+// the order saves (5.09 against 4.83 ms at 216^3, measured; runs of 64 / 256 are slower still).
+#ifndef NIN_LOCALITY_RUN
+#define NIN_LOCALITY_RUN 16
+#endif
+constexpr int kLocalityRun = NIN_LOCALITY_RUN;
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ void k_locality_keys(const double *__restrict__ coords, const int32_t *__restrict__ nodes, int32_t count, double lo,
+                                double scale, int32_t c1, int32_t c2, int32_t c3, uint32_t *__restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int32_t p = nodes[i & ~(int64_t)(kLocalityRun - 1)];   // the key of the run's first entry: the (stable) sort moves whole runs
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double t = (coords[3 * (size_t)p + k] - lo) * scale;
+        q[k] = t > 0.0 ? (t < 1023.0 ? (uint32_t)t : 1023u) : 0u;
+    }
+    const int32_t self = nodes[i];
+    const uint32_t piece = (uint32_t)(self >= c1) + (uint32_t)(self >= c2) + (uint32_t)(self >= c3);
+    keys[i] = (piece << 30) | spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+}
+// `list` (device, count entries, ascending node ids) -> the same entries in locality order; pieces = the pipeline's node boundaries
+int locality_order(const DeviceGrid &d, int32_t *list, int32_t count, const int32_t *chunk_node) {
+    if (count < 2048) return NIN_OK;
+    double lo = 0.0, hi = 0.0;
+    {   // the bounding cube: smallest and largest coordinate of any axis
+        double *mm = nullptr;
+        void *rt = nullptr;
+        size_t rb = 0, rb2 = 0;
+        const int n3 = 3 * d.v.n_points;
+        bool ok = hipMalloc((void **)&mm, 16) == hipSuccess &&
+                  hipcub::DeviceReduce::Min(nullptr, rb, d.v.coords, mm, n3) == hipSuccess &&
+                  hipcub::DeviceReduce::Max(nullptr, rb2, d.v.coords, mm + 1, n3) == hipSuccess &&
+                  hipMalloc(&rt, rb > rb2 ? rb : rb2) == hipSuccess;
+        rb = rb > rb2 ? rb : rb2;
+        ok = ok && hipcub::DeviceReduce::Min(rt, rb, d.v.coords, mm, n3) == hipSuccess &&
+             hipcub::DeviceReduce::Max(rt, rb, d.v.coords, mm + 1, n3) == hipSuccess;
+        double h2[2] = {0.0, 0.0};
+        ok = ok && hipMemcpy(h2, mm, 16, hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(mm); (void)hipFree(rt);
+        if (!ok) return fail(NIN_EHIP, "locality order: bounding cube: %s", hipGetErrorString(hipGetLastError()));
+        lo = h2[0]; hi = h2[1];
+    }
+    if (!(hi > lo)) return NIN_OK;
+    uint32_t *keys = nullptr, *keys_out = nullptr;
+    int32_t *list_out = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int rc = NIN_OK;
+    auto step = [&](hipError_t e) { if (e != hipSuccess && rc == NIN_OK) rc = fail(NIN_EHIP, "locality order: %s", hipGetErrorString(e)); return e == hipSuccess; };
+    if (step(hipMalloc((void **)&keys, (size_t)count * 4)) && step(hipMalloc((void **)&keys_out, (size_t)count * 4)) &&
+        step(hipMalloc((void **)&list_out, (size_t)count * 4))) {
+        hipLaunchKernelGGL(k_locality_keys, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, nullptr, d.v.coords, list, count, lo,
+                           1024.0 / (hi - lo), chunk_node[1], chunk_node[2], chunk_node[3], keys);
+        if (step(hipGetLastError()) && step(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, list, list_out, count)) &&
+            step(hipMalloc(&tmp, tmp_bytes)) &&
+            step(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, list, list_out, count)))
+            (void)step(hipMemcpy(list, list_out, (size_t)count * 4, hipMemcpyDeviceToDevice));
+    }
+    (void)hipFree(keys); (void)hipFree(keys_out); (void)hipFree(list_out); (void)hipFree(tmp);
+    return rc;
+}
 }  // namespace
 
 extern "C" {
@@ -400,11 +477,20 @@ int nin_grid_to_device(nin_grid *g, int device) {
         if (k.count && (rc = dev_upload(d, &lp, lists[c]))) return rc;
         k.nodes = const_cast<int32_t *>(lp);
     }
+    // interpolate()'s pipeline: its pieces' node boundaries (multiples of 64 nodes)
+    {
+        constexpr int K = DeviceGrid::kE2eChunks;
+        for (int k = 0; k <= K; ++k) d.chunk_node[k] = k == K ? (int32_t)P : (int32_t)((P * k / K) & ~(int64_t)63);
+    }
+    // (opt-in: at 216^3 it takes FETCH_SIZE of the cube-node kernel from 3.57 to 3.05 GiB per launch and costs 1.6 % of its time --
+    //  the kernel is bound by instruction issue, not by what it fetches; larger runs fetch MORE than node order does)
+    const bool locality = getenv("NIN_GLS_LOCALITY_ORDER") != nullptr;
     {
         d.hex8.count = (int32_t)hex8_list.size();
         const int32_t *lp = nullptr;
         if (d.hex8.count && (rc = dev_upload(d, &lp, hex8_list))) return rc;
         d.hex8.nodes = const_cast<int32_t *>(lp);
+        if (d.hex8.count && locality && (rc = locality_order(d, d.hex8.nodes, d.hex8.count, d.chunk_node))) return rc;
         if (d.hex8.count) {   // lane descriptors of the multifrontal kernel, one 16-byte record per list entry
             if ((rc = dev_alloc(d, &d.hex8_desc, (size_t)d.hex8.count * 4))) return rc;
             if (launch_hex8_desc(d.v, d.hex8.nodes, d.hex8.count, d.hex8_desc, nullptr)) return fail(NIN_EHIP, "hex8 descriptor kernel");
@@ -433,10 +519,10 @@ int nin_grid_to_device(nin_grid *g, int device) {
         d.gls_scratch_stride = need_max[kGlsClasses - 1] / 8;
         if ((rc = dev_alloc(d, &d.gls_scratch, (size_t)d.gls_scratch_slots * d.gls_scratch_stride))) return rc;
     }
-    // interpolate()'s pipeline: chunk boundaries (multiples of 64 nodes) and where they fall in every (ascending) list
+    // interpolate()'s pipeline: where the pieces' boundaries fall in every list (ascending here on the host; a list in locality
+    // order on the device is permuted inside the pieces only)
     {
         constexpr int K = DeviceGrid::kE2eChunks;
-        for (int k = 0; k <= K; ++k) d.chunk_node[k] = k == K ? (int32_t)P : (int32_t)((P * k / K) & ~(int64_t)63);
         auto cut = [&](int li, const std::vector<int32_t> &v) {
             for (int k = 0; k <= K; ++k)
                 d.chunk_off[li][k] = (int32_t)(std::lower_bound(v.begin(), v.end(), d.chunk_node[k]) - v.begin());

@@ -13,23 +13,26 @@ __device__ __forceinline__ double dpp_mov(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// 1/d and 1/sqrt(s) from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) plus two Newton steps: full double
-// precision to a few ulp, a third of the instructions and of the dependent latency of the IEEE division / sqrt
-// expansions.  They only feed the reflector scalars, where an ulp-level error is an ulp-level departure of H from
-// orthogonality (parity bar: 1e-10).
+// 1/d and 1/sqrt(s) from the hardware seeds (v_rcp_f64 / v_rsq_f64: 2^-24.4, measured -- tools/micro_seed.hip) plus ONE cubic
+// correction step each: r (1 + e + e^2), e = 1 - d r, and y (1 + e/2 + 3 e^2/8), e = 1 - s y^2 -- the error cubes, 1e-22
+// before rounding; measured 1.0 / 1.24 ulp over 2^-20 .. 2^20.  (One NEWTON step on the reciprocal leaves 2.2e-15 = 20 ulp,
+// which the FAN tensor's condition numbers turn into 3e-10 on the weights: tried in round 3, caught by the parity suite.)
+// A third of the instructions and of the dependent latency of the IEEE division / sqrt expansions.
 __device__ __forceinline__ double fast_rcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);
+    return fma(r, fma(e, e, e), r);
 }
 __device__ __forceinline__ double fast_rsqrt(double s) {
-    double y = __builtin_amdgcn_rsq(s);
-    double e = fma(-s * y, y, 1.0);            // 1 - s y^2
-    y = fma(y * e, fma(e, 0.375, 0.5), y);     // y (1 + e/2 + 3 e^2/8)
-    e = fma(-s * y, y, 1.0);
-    y = fma(y * e, 0.5, y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(s);
+    const double e = fma(-s * y, y, 1.0);            // 1 - s y^2
+    return fma(y * e, fma(e, 0.375, 0.5), y);          // y (1 + e/2 + 3 e^2/8)
+}
+// (the forms the cubic steps replace, kept for tools/micro_seed.hip)
+__device__ __forceinline__ double rcp_newton(double d, int steps) {
+    double r = __builtin_amdgcn_rcp(d);
+    for (int i = 0; i < steps; ++i) r = fma(fma(-d, r, 1.0), r, r);
+    return r;
 }
 
 // Householder scalars for the column (alpha, x), ss = |x|^2:  beta = -sign(alpha) |(alpha, x)| (dlarfg);
@@ -41,30 +44,13 @@ struct House {
 // The same without the x = 0 branch.  x = 0, alpha != 0 needs none: beta = -alpha, v = (2 alpha, 0), H flips the sign of
 // the pivot row -- orthogonal all the same.  A column that is zero altogether (S = 0) turns into NaNs here, which the
 // caller's final finiteness test maps to the zero row a rank-deficient system gets anyway.
-#ifdef NIN_HOUSE_ONE_STEP
-// one correction step each (kernels_gls_hex8mf.hip): the cubic step takes v_rsq_f64's 2^-26 to rounding level, the Newton step v_rcp_f64's to ~2^-52
-__device__ __forceinline__ double fast_rcp1(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    return fma(fma(-d, r, 1.0), r, r);
-}
-__device__ __forceinline__ double fast_rsqrt1(double s) {
-    double y = __builtin_amdgcn_rsq(s);
-    const double e = fma(-s * y, y, 1.0);
-    return fma(y * e, fma(e, 0.375, 0.5), y);
-}
-#define NIN_HOUSE_RCP fast_rcp1
-#define NIN_HOUSE_RSQRT fast_rsqrt1
-#else
-#define NIN_HOUSE_RCP fast_rcp
-#define NIN_HOUSE_RSQRT fast_rsqrt
-#endif
 __device__ __forceinline__ House house_unguarded(double alpha, double ss) {
     const double S = fma(alpha, alpha, ss);
-    const double rs = NIN_HOUSE_RSQRT(S), sq = S * rs;
+    const double rs = fast_rsqrt(S), sq = S * rs;
     House h;
     h.beta = -copysign(sq, alpha);
     h.vp = alpha - h.beta;
-    h.g = NIN_HOUSE_RCP(fma(fabs(alpha), sq, S));
+    h.g = fast_rcp(fma(fabs(alpha), sq, S));
     h.rinv = -copysign(rs, alpha);                          // 1 / beta
     return h;
 }

@@ -36,10 +36,6 @@
 #include <cstdlib>
 
 #include "device_grid.hpp"
-// the reflector scalars with ONE correction step behind the hardware seeds in this file (gls_device_math.hpp): the cubic step
-// takes v_rsq_f64's 2^-26 to rounding level, the Newton step v_rcp_f64's to ~2^-52 -- an ulp-level departure of H from
-// orthogonality; 90 FP64 instructions per pass less (row-scaled error against the oracle 3.7e-14 -> 5.5e-14, tools/err_hex.py)
-#define NIN_HOUSE_ONE_STEP
 #include "gls_device_math.hpp"
 #include "hex8_desc.hpp"
 #include "launch.hpp"

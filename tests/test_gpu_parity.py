@@ -218,6 +218,28 @@ def test_gpu_cube_kernel_forms(oracle_lib, monkeypatch, one_wave):
     assert np.array_equal(ws, w[sub]) and np.array_equal(nws, nw[sub])
 
 
+def test_gpu_cube_list_in_locality_order(monkeypatch):
+    """NIN_GLS_LOCALITY_ORDER: the cube-node kernel's list in Morton order of the node coordinates (runs of 16 entries, inside the
+    pieces of interpolate()'s pipeline).  A node's arithmetic does not depend on its neighbours in the list: the weights are
+    bit-identical to the default (node order), through prepare_interpolator and through the pipelined interpolate()."""
+    mesh = M.hex_mesh(30, 26, 22, jitter=0.15, seed=8)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(0, 0.0), seed=3)
+    monkeypatch.setenv("NIN_E2E_MIN_NODES", "1024")
+    got = {}
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv("NIN_GLS_LOCALITY_ORDER", "1")
+        I = _interp()
+        I.load_mesh(mesh_obj=mesh)
+        w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+        W, neu = I.interpolate("u", "gls")
+        got[on] = (w, nw, W.indptr.copy(), W.indices.copy(), W.data.copy(), neu)
+        assert I.grid.gls_plan()["hex8"] == 29 * 25 * 21
+    for a, b in zip(got[False], got[True]):
+        assert np.array_equal(a, b)
+    assert np.count_nonzero(got[True][0]) > 8 * 29 * 25 * 21 - 10
+
+
 @pytest.mark.parametrize("kind", ["tet", "wedge", "mixed"])
 def test_gpu_block_kernel_where_mfw_would_run(oracle_lib, monkeypatch, kind):
     """Interior nodes of tetrahedron / wedge / mixed meshes go to the one-wavefront multifrontal kernel by default; with
