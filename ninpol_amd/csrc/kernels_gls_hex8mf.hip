@@ -477,18 +477,23 @@ __global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, cons
     }
 }
 
-// ---- the same node on TWO wavefronts per SIMD ------------------------------------------------------------------------------
+// ---- the same node on TWO wavefronts per SIMD (round 3: the default; the kernel above stays behind NIN_HEX8_ONE_WAVE) --------
 // A lone wavefront cannot keep the FP64 pipe busy (tools/micro_mfma64.hip: one wave issues a v_fma_f64 every 8.5 cycles, two
 // waves together one every 5.9), and the kernel above is one wave per SIMD because its peak -- the end of phase 1, where the
-// finished fill rows, the panel, a block in flight and the face records coexist -- is ~340 registers.  This variant fits 256:
-//   * phase 1 takes the odd-slot blocks ONE COLUMN at a time (10 doubles in flight, not 30), and the first 35 finished fill
-//     entries of a lane (c, odd slot 0, the first column of slot 1) wait in LDS -- lane-private slots, [slot][lane], no
-//     conflicts, no synchronisation -- until the panel and the face records are gone;
-//   * phase 2 computes each column's dot where it is used (no array of partial dots across the scalar chain: the OTHER wave
-//     fills that latency now), with u and s in the LDS slots the fill entries have left;
-//   * plain loads at the top of a pass, static round-robin over the groups (the other wave covers the latency; nothing is in
-//     flight that the compiler does not know about).
-// Same arithmetic, same order of the Householder steps: results differ from the kernel above by rounding only.
+// finished fill rows, the panel, a block in flight and the face records coexist -- is ~340 registers.  This one fits 256:
+//   * phase 1 takes the columns of the odd cells ONE at a time (10 doubles in flight, not 30) and in FACE order (a lane's three
+//     faces; the slot it has no face on is never computed), each through the reflectors' mutual products (w2_column); the
+//     first 35 finished fill entries of a lane (c, face 0, the first column of face 1) wait in LDS -- lane-private slots,
+//     [slot][lane], no conflicts, no synchronisation -- until the panel and the face records are gone;
+//   * phase 2 forms each column's dot where it is used (the other wave fills the scalar chain's latency), with u and s in the
+//     LDS slots the fill entries have left;
+//   * the index levels of the next pass (list entry -> CSR row starts, coordinates -> cell / face ids) come in by LDS-DMA
+//     during this one (nothing in flight that the compiler could move or spill); geometry and permeability by plain loads at
+//     the top of the pass; a per-XCD work queue (the SIMD issues its older wave first: equal shares finish 4.0 / 5.85 ms apart).
+// With two waves the SIMD is bound by instruction issue (FP64 at ~2.6 ns an instruction, everything else at ~1): every change
+// since the first version that fitted was a cut in instructions -- 4 159 -> 4 096 a pass, of them FP64 2 926 -> 2 426; executed
+// flops per node 20.5 k (kernel above) -> 16.7 k against 15.9 k algorithmic.  5.95 -> 4.8 .. 5.0 ms per launch at 216^3.
+// Same arithmetic as the kernel above up to the order of a few sums: results differ by rounding only.
 #ifdef NIN_W2_FENCE_COLUMNS
 #define NIN_W2_COLUMN_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
