@@ -1,6 +1,7 @@
 // abi.hip -- the extern "C" surface declared in include/ninpol_amd.h.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <cmath>
 
 #include <algorithm>
 #include <chrono>
@@ -146,11 +147,19 @@ bool lookup_array(nin_grid *g, const std::string &name, ArrayRef *r) {
 
 
 // ---- locality order of a kernel's node list --------------------------------------------------------------------------------
-// A list in node order walks the mesh the way its nodes are numbered (a structured mesh: along x), and a node shares its cells
-// and faces with neighbours that are a whole row or plane of the numbering away: with 2 x 256 groups of a kernel in flight per
-// XCD the data comes in again for every plane (FETCH_SIZE 3.58 GiB per launch at 216^3 against 2.6 with half as many waves).
-// So the list is put in Morton order of the node coordinates (10 bits an axis over the mesh's bounding cube) -- inside each piece
-// of interpolate()'s pipeline, whose pieces stay sub-ranges of the list.
+// A list in node order walks the mesh the way its nodes are numbered (a structured mesh: along x, row by row, plane by plane),
+// and a node shares its cells and faces with neighbours that are a whole plane of the numbering away: with 2 x 256 groups of
+// the cube-node kernel in flight per XCD the data comes in again for every plane (FETCH_SIZE 3.58 GiB per launch at 216^3
+// against 2.6 with half as many waves).  So the list is reordered by where the nodes ARE -- inside each piece of interpolate()'s
+// pipeline, whose pieces stay sub-ranges of the list:
+//   default   strips of 16 mesh rows (axis 1 quantised to ~cbrt(P) levels) walked plane by plane (axis 2), node order inside:
+//             the rows a plane apart meet in the 4 MB L2 and the requests stay as coalesced as the numbering makes them --
+//             FETCH_SIZE 3.58 -> 1.97 GiB (traffic = the algorithmic bytes), 4.90 -> 4.78 ms in one session (s4 / s8 / s32: 4.84 /
+//             4.85 / 4.82);
+//   "m"       Morton order of the coordinates (10 bits an axis over the bounding cube): 3.05 GiB but 1.6 % SLOWER than node order
+//             -- uncoalesced requests are instructions too, and the kernel is bound by what it issues;
+//   "off"     node order.
+// Any order gives the same weights bit for bit (a node's arithmetic does not depend on its neighbours in the list; tested).
 // Runs of 16 consecutive entries (one pass of a 16-nodes-per-wavefront kernel) move as one: inside a run the rows of the CSR
 // tables and of the output stay next to each other -- single nodes in Morton order cost more in uncoalesced requests than
 // the order saves (5.09 against 4.83 ms at 216^3, measured; runs of 64 / 256 are slower still).
@@ -165,8 +174,11 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
+// strip > 0: instead, strips of `strip` mesh rows (axis 1 at ~cbrt(P) levels) walked plane by plane (axis 2), node order inside:
+// the rows a plane apart meet in the L2 while the requests stay as coalesced as the numbering makes them
 __global__ void k_locality_keys(const double *__restrict__ coords, const int32_t *__restrict__ nodes, int32_t count, double lo,
-                                double scale, int32_t c1, int32_t c2, int32_t c3, uint32_t *__restrict__ keys) {
+                                double scale, int32_t c1, int32_t c2, int32_t c3, int32_t strip, double lscale,
+                                uint32_t *__restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const int32_t p = nodes[i & ~(int64_t)(kLocalityRun - 1)];   // the key of the run's first entry: the (stable) sort moves whole runs
@@ -178,6 +190,13 @@ __global__ void k_locality_keys(const double *__restrict__ coords, const int32_t
     }
     const int32_t self = nodes[i];
     const uint32_t piece = (uint32_t)(self >= c1) + (uint32_t)(self >= c2) + (uint32_t)(self >= c3);
+    if (strip > 0) {
+        const double ty = (coords[3 * (size_t)p + 1] - lo) * lscale, tz = (coords[3 * (size_t)p + 2] - lo) * lscale;
+        const uint32_t yq = ty > 0.0 ? (ty < 32767.0 ? (uint32_t)(ty + 0.5) : 32767u) : 0u;
+        const uint32_t zq = tz > 0.0 ? (tz < 32767.0 ? (uint32_t)(tz + 0.5) : 32767u) : 0u;
+        keys[i] = (piece << 30) | ((yq / (uint32_t)strip) << 15) | zq;
+        return;
+    }
     keys[i] = (piece << 30) | spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
 }
 // `list` (device, count entries, ascending node ids) -> the same entries in locality order; pieces = the pipeline's node boundaries
@@ -211,8 +230,11 @@ int locality_order(const DeviceGrid &d, int32_t *list, int32_t count, const int3
     auto step = [&](hipError_t e) { if (e != hipSuccess && rc == NIN_OK) rc = fail(NIN_EHIP, "locality order: %s", hipGetErrorString(e)); return e == hipSuccess; };
     if (step(hipMalloc((void **)&keys, (size_t)count * 4)) && step(hipMalloc((void **)&keys_out, (size_t)count * 4)) &&
         step(hipMalloc((void **)&list_out, (size_t)count * 4))) {
+        const char *mode = getenv("NIN_GLS_LOCALITY_ORDER");
+        const int32_t strip = !mode ? 16 : mode[0] == 's' ? (mode[1] ? atoi(mode + 1) : 16) : 0;   // default: strips of 16 rows; "m": Morton
+        const double levels = std::cbrt((double)d.v.n_points) - 1.0;                          // mesh intervals per axis of a cube of this many nodes
         hipLaunchKernelGGL(k_locality_keys, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, nullptr, d.v.coords, list, count, lo,
-                           1024.0 / (hi - lo), chunk_node[1], chunk_node[2], chunk_node[3], keys);
+                           1024.0 / (hi - lo), chunk_node[1], chunk_node[2], chunk_node[3], strip, (levels > 1.0 ? levels : 1.0) / (hi - lo), keys);
         if (step(hipGetLastError()) && step(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_out, list, list_out, count)) &&
             step(hipMalloc(&tmp, tmp_bytes)) &&
             step(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, list, list_out, count)))
@@ -482,9 +504,9 @@ int nin_grid_to_device(nin_grid *g, int device) {
         constexpr int K = DeviceGrid::kE2eChunks;
         for (int k = 0; k <= K; ++k) d.chunk_node[k] = k == K ? (int32_t)P : (int32_t)((P * k / K) & ~(int64_t)63);
     }
-    // (opt-in: at 216^3 it takes FETCH_SIZE of the cube-node kernel from 3.57 to 3.05 GiB per launch and costs 1.6 % of its time --
-    //  the kernel is bound by instruction issue, not by what it fetches; larger runs fetch MORE than node order does)
-    const bool locality = getenv("NIN_GLS_LOCALITY_ORDER") != nullptr;
+    // (NIN_GLS_LOCALITY_ORDER: "s<rows>" = strips of that many mesh rows, the default s16; "m" = Morton order; "off" = node order)
+    const char *lo_env = getenv("NIN_GLS_LOCALITY_ORDER");
+    const bool locality = !(lo_env && (lo_env[0] == 'o' || lo_env[0] == '0'));
     {
         d.hex8.count = (int32_t)hex8_list.size();
         const int32_t *lp = nullptr;

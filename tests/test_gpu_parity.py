@@ -219,25 +219,29 @@ def test_gpu_cube_kernel_forms(oracle_lib, monkeypatch, one_wave):
 
 
 def test_gpu_cube_list_in_locality_order(monkeypatch):
-    """NIN_GLS_LOCALITY_ORDER: the cube-node kernel's list in Morton order of the node coordinates (runs of 16 entries, inside the
-    pieces of interpolate()'s pipeline).  A node's arithmetic does not depend on its neighbours in the list: the weights are
-    bit-identical to the default (node order), through prepare_interpolator and through the pipelined interpolate()."""
+    """NIN_GLS_LOCALITY_ORDER: the cube-node kernel's list in strips of mesh rows walked plane by plane (the default), in Morton
+    order of the node coordinates ("m"), in node order ("off") -- runs of 16 entries, inside the pieces of interpolate()'s
+    pipeline.  A node's arithmetic does not depend on its neighbours in the list: the weights are bit-identical in all three,
+    through prepare_interpolator and through the pipelined interpolate()."""
     mesh = M.hex_mesh(30, 26, 22, jitter=0.15, seed=8)
     M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(0, 0.0), seed=3)
     monkeypatch.setenv("NIN_E2E_MIN_NODES", "1024")
     got = {}
-    for on in (False, True):
-        if on:
-            monkeypatch.setenv("NIN_GLS_LOCALITY_ORDER", "1")
+    for mode in ("off", None, "m", "s3"):
+        if mode:
+            monkeypatch.setenv("NIN_GLS_LOCALITY_ORDER", mode)
+        else:
+            monkeypatch.delenv("NIN_GLS_LOCALITY_ORDER", raising=False)
         I = _interp()
         I.load_mesh(mesh_obj=mesh)
         w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
         W, neu = I.interpolate("u", "gls")
-        got[on] = (w, nw, W.indptr.copy(), W.indices.copy(), W.data.copy(), neu)
+        got[mode] = (w, nw, W.indptr.copy(), W.indices.copy(), W.data.copy(), neu)
         assert I.grid.gls_plan()["hex8"] == 29 * 25 * 21
-    for a, b in zip(got[False], got[True]):
-        assert np.array_equal(a, b)
-    assert np.count_nonzero(got[True][0]) > 8 * 29 * 25 * 21 - 10
+    for mode in (None, "m", "s3"):
+        for a, b in zip(got["off"], got[mode]):
+            assert np.array_equal(a, b), mode
+    assert np.count_nonzero(got[None][0]) > 8 * 29 * 25 * 21 - 10
 
 
 @pytest.mark.parametrize("kind", ["tet", "wedge", "mixed"])
