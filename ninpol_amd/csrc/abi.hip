@@ -1007,8 +1007,8 @@ int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t
     // Neumann flags only: the reference's callers do `weights.dot(u)` per field with the same matrix)
     int rc = nin_weights_device(g, method, nullptr, 0, 1, d.apply_weights, dev_neumann_ws, stream_);
     if (rc) return rc;
-    rc = n_fields == 1 ? launch_apply(d.v, d.apply_weights, dev_u_cells, dev_node_values, stream)
-                       : launch_apply_fields(d.v, d.apply_weights, dev_u_cells, n_fields, dev_node_values, stream);
+    rc = n_fields == 1 ? launch_apply(d.v, d.apply_weights, dev_u_cells, dev_node_values, (int32_t)g->h.mx_elems_per_point, stream)
+                       : launch_apply_fields(d.v, d.apply_weights, dev_u_cells, n_fields, dev_node_values, (int32_t)g->h.mx_elems_per_point, stream);
     if (rc) return fail(rc, "launch failed");
     return NIN_OK;
 }

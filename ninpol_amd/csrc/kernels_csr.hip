@@ -60,22 +60,25 @@ __global__ __launch_bounds__(256) void nin_compact_kernel(GridView g, const doub
 // row order; the 64 rows of a wavefront's nodes are one contiguous run of data / esup, copied HBM -> LDS cooperatively (whole
 // lines; a lane reading its own row straight from HBM strides 64 bytes: FETCH_SIZE 2.65 GB raw for 0.97 GB of rows, 0.84 ms at
 // 10 M cells), u is gathered (L2).  NF fields at once (u: [k][n_elems], values: [k][n_points]): the run is staged once.
-constexpr int kApplyCap = 1024;   // entries of LDS per wavefront (12 KiB); a longer run goes straight from HBM
+constexpr int kApplyCap = 1024;   // most entries of LDS a wavefront may own (12 KiB); a longer run goes straight from HBM
+// `cap`: the entries of LDS each wavefront owns in THIS launch (64 x the longest row, at most kApplyCap: 6 KiB a wave on a
+// hexahedron mesh -- six workgroups per CU instead of three; the kernel lives on loads in flight: 0.56 -> 0.33 ms at 10 M cells)
 template <int NF>
 __global__ __launch_bounds__(256) void nin_apply_kernel(GridView g, const double *__restrict__ data,
                                                         const double *__restrict__ u, int32_t k0, int32_t k,
-                                                        double *__restrict__ values) {
-    __shared__ double wl[4][kApplyCap];
-    __shared__ int32_t cl[4][kApplyCap];
+                                                        double *__restrict__ values, int32_t cap) {
+    extern __shared__ double apply_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *const wl = apply_lds + (size_t)wave * cap;
+    int32_t *const cl = reinterpret_cast<int32_t *>(apply_lds + 4 * (size_t)cap) + (size_t)wave * cap;
     const size_t E = (size_t)g.n_elems, P = (size_t)g.n_points;
     const int32_t n_tiles = (g.n_points + 63) / 64;
     for (int32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         const int32_t p0 = tile * 64, p = p0 + lane, pe = p0 + 64 < g.n_points ? p0 + 64 : g.n_points;
         const int32_t run_b = g.esup_ptr[p0], run_e = g.esup_ptr[pe], len = run_e - run_b;
-        const bool staged = len <= kApplyCap, live = p < g.n_points;
+        const bool staged = len <= cap, live = p < g.n_points;
         if (staged) {
-            for (int32_t i = lane; i < len; i += 64) { wl[wave][i] = data[run_b + i]; cl[wave][i] = g.esup[run_b + i]; }
+            for (int32_t i = lane; i < len; i += 64) { wl[i] = data[run_b + i]; cl[i] = g.esup[run_b + i]; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -85,9 +88,26 @@ __global__ __launch_bounds__(256) void nin_apply_kernel(GridView g, const double
             double acc[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[f] = 0.0;
-            for (int32_t q = b; q < e; ++q) {
-                const double w = staged ? wl[wave][q - run_b] : data[q];
-                const size_t c = (size_t)(staged ? cl[wave][q - run_b] : g.esup[q]);
+            // eight entries at a time: their gathers of u are issued together, the sums stay in row order
+            int32_t q = b;
+            for (; q + 8 <= e; q += 8) {
+                double w8[8], u8[8][NF];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    w8[j] = staged ? wl[q + j - run_b] : data[q + j];
+                    const size_t c = (size_t)(staged ? cl[q + j - run_b] : g.esup[q + j]);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) u8[j][f] = k0 + f < k ? u[(size_t)(k0 + f) * E + c] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) acc[f] += w8[j] * u8[j][f];
+                }
+            }
+            for (; q < e; ++q) {
+                const double w = staged ? wl[q - run_b] : data[q];
+                const size_t c = (size_t)(staged ? cl[q - run_b] : g.esup[q]);
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
                     if (k0 + f < k) acc[f] += w * u[(size_t)(k0 + f) * E + c];
@@ -136,18 +156,26 @@ int launch_pad_centroids(const double *src, int64_t n_elems, double *dst, hipStr
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int launch_apply(const GridView &g, const double *data, const double *u, double *values, hipStream_t stream) {
-    hipLaunchKernelGGL(nin_apply_kernel<1>, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, u, 0, 1, values);
+// LDS entries per wavefront for rows of at most `mx_row` entries: 64 rows, in steps of 64, at most kApplyCap
+static int32_t apply_cap(int32_t mx_row) {
+    int64_t c = 64 * (int64_t)(mx_row > 0 ? mx_row : 1);
+    return (int32_t)(c > kApplyCap ? kApplyCap : c);
+}
+int launch_apply(const GridView &g, const double *data, const double *u, double *values, int32_t mx_row, hipStream_t stream) {
+    const int32_t cap = apply_cap(mx_row);
+    hipLaunchKernelGGL(nin_apply_kernel<1>, dim3(grid_for(g.n_points)), dim3(256), (size_t)cap * 4 * 12, stream, g, data, u, 0, 1, values, cap);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // k fields: four per pass over the weights (the rows of a wavefront are staged once per pass)
-int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values,
+int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values, int32_t mx_row,
                         hipStream_t stream) {
+    const int32_t cap = apply_cap(mx_row);
+    const size_t lds = (size_t)cap * 4 * 12;
     for (int32_t k0 = 0; k0 < k; k0 += 4) {
-        if (k - k0 >= 3) hipLaunchKernelGGL(nin_apply_kernel<4>, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, u, k0, k, values);
-        else if (k - k0 == 2) hipLaunchKernelGGL(nin_apply_kernel<2>, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, u, k0, k, values);
-        else hipLaunchKernelGGL(nin_apply_kernel<1>, dim3(grid_for(g.n_points)), dim3(256), 0, stream, g, data, u, k0, k, values);
+        if (k - k0 >= 3) hipLaunchKernelGGL(nin_apply_kernel<4>, dim3(grid_for(g.n_points)), dim3(256), lds, stream, g, data, u, k0, k, values, cap);
+        else if (k - k0 == 2) hipLaunchKernelGGL(nin_apply_kernel<2>, dim3(grid_for(g.n_points)), dim3(256), lds, stream, g, data, u, k0, k, values, cap);
+        else hipLaunchKernelGGL(nin_apply_kernel<1>, dim3(grid_for(g.n_points)), dim3(256), lds, stream, g, data, u, k0, k, values, cap);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

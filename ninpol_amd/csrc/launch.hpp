@@ -52,9 +52,9 @@ int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr
 int launch_rows_range(const GridView &g, int method_ls, int32_t n_points, int32_t p_begin, int32_t p_end, int32_t mx_row,
                       double *out, double *nws, hipStream_t stream);
 
-int launch_apply(const GridView &g, const double *data, const double *u, double *values, hipStream_t stream);
+int launch_apply(const GridView &g, const double *data, const double *u, double *values, int32_t mx_row, hipStream_t stream);
 // k fields at once: u [k][n_elems], values [k][n_points]
-int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values,
+int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values, int32_t mx_row,
                         hipStream_t stream);
 
 // GLS launch plan (grid_device.hip): size class of every node (255 = the hex8 kernel, 254 / 253 / 252 = the one-wavefront multifrontal kernel: two-coloured nodes large / small, general kind) and, per class, the
