@@ -83,6 +83,8 @@ struct DeviceGrid {
     int32_t *hex8_desc = nullptr;   // [4 * hex8.count] lane descriptors (hex8_desc.hpp)
     GlsClass mfw[3];   // kernels_gls_mfw.hip (mfw_desc.hpp): two-coloured nodes large (Kuhn tetrahedra) / small (wedges), general kind
     uint32_t *mfw_desc[3] = {nullptr, nullptr, nullptr};   // [kMfwDescWords * mfw[i].count] descriptor words
+    GlsClass quad4;      // kernels_gls_quad4.hip: nodes inside a boundary face of a hexahedron mesh (4 cells, 4 + 4 faces)
+    int32_t *quad4_desc = nullptr;   // [2 * quad4.count] descriptor words
     GlsClass small[3];   // kernels_gls_mfw.hip, nin_gls_small_kernel: nodes with at most 4 / 8 / 12 cells and 64 rows that no kernel above takes
     double *gls_scratch = nullptr;  // global-memory systems for the oversize class
     int64_t gls_scratch_stride = 0; // doubles per wave slot
@@ -100,10 +102,10 @@ struct DeviceGrid {
     void *ev_weights = nullptr, *ev_scan = nullptr;   // hipEvent_t: weights written / row pointers scanned
     // interpolate()'s pipeline (abi.hip, interpolate_chunked): the node range is cut into kE2eChunks pieces at multiples of 64 nodes;
     // every GLS list is ascending, so a piece is a sub-range of each: chunk_off[list][k] .. chunk_off[list][k + 1]
-    // (lists 0 .. kGlsClasses - 1: the block kernel's classes, then the cube-node kernel, the three mfw kinds, the three small kinds)
+    // (lists 0 .. kGlsClasses - 1: the block kernel's classes, then the cube-node kernel, the three mfw kinds, the three small kinds, the quad nodes)
     static constexpr int kE2eChunks = 4;
     int32_t chunk_node[kE2eChunks + 1] = {0, 0, 0, 0, 0};
-    int32_t chunk_off[kGlsClasses + 7][kE2eChunks + 1] = {};
+    int32_t chunk_off[kGlsClasses + 8][kE2eChunks + 1] = {};
     bool chunkable = false;
     bool gls_too_large = false;     // some node's system has more rows than the scratch kernel handles (1024)
 };

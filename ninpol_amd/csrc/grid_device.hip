@@ -27,6 +27,7 @@
 #include "device_grid.hpp"
 #include "grid_host.hpp"
 #include "hex8_desc.hpp"
+#include "quad4_desc.hpp"
 #include "mfw_desc.hpp"
 #include "launch.hpp"
 
@@ -573,6 +574,11 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
             return;
         }
         if (kind == 2 && (use_group & 4)) { node_class[p] = 252; return; }
+    }
+    // nodes inside a boundary face of a hexahedron mesh: two lanes per node (kernels_gls_quad4.hip)
+    if ((use_group & 16) && !force_global && ne == 4 && nf == 8 && nbf == 4 && g.dim == 3) {
+        int32_t d2[2];
+        if (quad4_descriptor(g, (int32_t)p, d2)) { node_class[p] = 248; return; }
     }
     // small nodes (in practice: boundary nodes): the one-wavefront dense kernel, lane = row (kernels_gls_mfw.hip, nin_gls_small_kernel)
     if ((use_group & 8) && !force_global && g.dim == 3 && ne <= 12 && nf <= 48 && ne + 3 * (nf - nbf) + nbf <= 64) {

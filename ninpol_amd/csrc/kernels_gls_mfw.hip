@@ -1147,7 +1147,8 @@ int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc
 int launch_gls_small(const GridView &g, const int32_t *nodes, int32_t count, int kind, int add_neumann, double *out, double *nws,
                      hipStream_t stream) {
     if (count <= 0) return 0;
-    int64_t blocks = ((int64_t)count + 255) / 256;              // a wave looks at 64 list entries per round
+    int64_t blocks = ((int64_t)count + 31) / 32;                // a wave looks at up to 64 list entries per round, n_waves apart: about
+                                                                // 8 per wave while the chip has room (the nodes it computes go one after the other)
     const int64_t cap = 256 * (kind == 0 ? 4 : kind == 1 ? 3 : 2) * 2;
     if (blocks > cap) blocks = cap;
     if (kind == 0) hipLaunchKernelGGL(nin_gls_small_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, count, add_neumann, out, nws);

@@ -38,6 +38,11 @@ int launch_mfw_desc(const GridView &g, const int32_t *nodes, int32_t count, uint
 int launch_gls_mfw(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int kind, int add_neumann,
                    double *out, double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_mfw();
+// quad nodes (kernels_gls_quad4.hip: 4 cells, 4 internal + 4 boundary faces -- the nodes inside a boundary face of a hexahedron
+// mesh): 2 lanes per node; `desc` = 2 descriptor words per list entry (quad4_desc.hpp), filled by launch_quad4_desc
+int launch_quad4_desc(const GridView &g, const int32_t *nodes, int32_t count, int32_t *desc, hipStream_t stream);
+int launch_gls_quad4(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann, double *out,
+                     double *nws, hipStream_t stream);
 // the one-wavefront dense kernel for small nodes (kernels_gls_mfw.hip): kind 0 / 1 / 2 = at most 4 / 8 / 12 cells, at most 64 rows
 int launch_gls_small(const GridView &g, const int32_t *nodes, int32_t count, int kind, int add_neumann, double *out, double *nws,
                      hipStream_t stream);

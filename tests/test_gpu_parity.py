@@ -218,6 +218,38 @@ def test_gpu_cube_kernel_forms(oracle_lib, monkeypatch, one_wave):
     assert np.array_equal(ws, w[sub]) and np.array_equal(nws, nw[sub])
 
 
+@pytest.mark.parametrize("axis,side", [(0, 0.0), (1, 1.0), (2, 0.0), (2, 1.0)])
+def test_gpu_quad_node_kernel(oracle_lib, monkeypatch, axis, side):
+    """The nodes inside a boundary face of a hexahedron mesh (4 cells, 4 internal + 4 boundary faces) on a Neumann plane: the
+    two-lanes-per-node kernel (kernels_gls_quad4.hip) against the oracle and against the small-node kernel that serves them
+    when it is switched off; planes of either orientation and side (which cell of a face is its first differs), a ragged last
+    group, Dirichlet quad nodes of the other faces in the same list (zero rows), target subsets."""
+    mesh = M.hex_mesh(13, 11, 9, jitter=0.15, seed=4)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(axis, side), seed=6)
+    o = oracle_lib.OracleInterpolator("port", threads=8)
+    o.load_mesh(mesh)
+    wo, no = o.prepare("gls", "u")
+    got = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("NIN_GLS_NO_QUAD4", "1")
+        I = _interp()
+        I.load_mesh(mesh_obj=mesh)
+        I.grid.to_device(0)
+        plan = I.grid.gls_plan()
+        assert plan["quad4"] == (0 if off else 2 * (12 * 10 + 12 * 8 + 10 * 8))
+        w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+        assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL, off
+        assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL, off
+        got[off] = (w, nw, I)
+    flag = np.asarray(mesh.point_data["neumann_flag_u"]).astype(bool)
+    ne = np.diff(np.asarray(got[False][2].grid.esup_ptr))
+    assert np.count_nonzero(got[False][1][flag & (ne == 4)]) > 50          # the plane's quad nodes carry a Neumann value
+    sub = np.sort(np.random.default_rng(1).choice(mesh.points.shape[0], size=317, replace=False)).astype(np.int64)
+    ws, nws = got[False][2].prepare_interpolator("gls", "u", sub)
+    assert np.array_equal(ws, got[False][0][sub]) and np.array_equal(nws, got[False][1][sub])
+
+
 def test_gpu_cube_list_in_locality_order(monkeypatch):
     """NIN_GLS_LOCALITY_ORDER: the cube-node kernel's list in strips of mesh rows walked plane by plane (the default), in Morton
     order of the node coordinates ("m"), in node order ("off") -- runs of 16 entries, inside the pieces of interpolate()'s
@@ -469,9 +501,10 @@ _GLS_ROUTES = {
     "mfw_row_lanes": ("NIN_MFW_NO_STRIPS",),                              # its second form (round 2's default) where the strip form runs now
     "mfw_small_strips": ("NIN_GLS_NO_GROUP", "NIN_MFW_SMALL_STRIPS"),     # the strip form in the small instantiation (wedge / cube nodes)
     "no_general_kind": ("NIN_GLS_NO_MFW_GENERAL",),                       # general-kind nodes -> block kernel
-    "no_small_kernel": ("NIN_GLS_NO_SMALL",),                             # boundary nodes -> block kernel (round 2's route)
+    "no_quad_kernel": ("NIN_GLS_NO_QUAD4",),                              # nodes inside a boundary face -> small-node kernel
+    "no_small_kernel": ("NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4"),          # boundary nodes -> block kernel (round 2's route)
     "small_where_it_fits": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"),        # the small-node kernel for every node of <= 12 cells and <= 64 rows
-    "block_only": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_SMALL"),   # block kernel, 1 / 2 / 4 / 8 wavefronts per node
+    "block_only": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4"),   # block kernel, 1 / 2 / 4 / 8 wavefronts per node
     "global_scratch": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_FORCE_GLOBAL"),   # the wave kernel
 }
 
@@ -511,9 +544,11 @@ def test_gpu_gls_degenerate_zero_pivot_column(monkeypatch, kind):
     assert plans["no_general_kind"]["mfw_general"] == 0
     small = ("small4", "small8", "small12")
     assert sum(d[k] for k in small) > 0 and all(plans["no_small_kernel"][k] == 0 for k in small)
+    assert (d["quad4"] > 0 or kind == "tet") and plans["no_quad_kernel"]["quad4"] == 0   # (wedge meshes have quad nodes too: their lateral faces)
+    assert sum(plans["no_quad_kernel"][k] for k in small) == sum(d[k] for k in small) + d["quad4"]
     assert sum(plans["small_where_it_fits"][k] for k in small) >= sum(d[k] for k in small) + (d["hex8"] if kind == "hex" else 0)
     for route in ("block_only", "global_scratch"):
-        assert all(plans[route][k] == 0 for k in ("hex8", "mfw_large", "mfw_small", "mfw_general") + small), route
+        assert all(plans[route][k] == 0 for k in ("hex8", "mfw_large", "mfw_small", "mfw_general", "quad4") + small), route
     assert all(sum(p.values()) == I.grid.n_points for p in plans.values())
 
 
@@ -541,7 +576,7 @@ def test_gpu_gls_fan_permeability(oracle_lib, n):
     # the same nodes through the generic kernels (cube-node kernel off): the bound is a property of the case, not of a kernel
     if n == 32:
         import os
-        for switches in (("NIN_GLS_NO_GROUP",), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_SMALL")):
+        for switches in (("NIN_GLS_NO_GROUP",), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4")):
             for sw in switches:
                 os.environ[sw] = "1"
             try:
