@@ -501,6 +501,17 @@ int nin_grid_to_device(nin_grid *g, int device) {
         if (k.count && (rc = dev_upload(d, &lp, lists[c]))) return rc;
         k.nodes = const_cast<int32_t *>(lp);
     }
+    {   // every node the cube-node kernel does not take, ascending: what the fused apply leaves to the list kernel
+        std::vector<int32_t> rest;
+        rest.reserve((size_t)P - hex8_list.size());
+        for (int64_t p = 0; p < P; ++p)
+            if (g->node_class[p] != 255) rest.push_back((int32_t)p);
+        d.noncube_count = (int32_t)rest.size();
+        const int32_t *lp = nullptr;
+        if (d.noncube_count && (rc = dev_upload(d, &lp, rest))) return rc;
+        d.noncube_nodes = lp;
+        d.noncube_nodes_ready = true;
+    }
     // interpolate()'s pipeline: its pieces' node boundaries (multiples of 64 nodes)
     {
         constexpr int K = DeviceGrid::kE2eChunks;
@@ -624,6 +635,16 @@ static int launch_class(DeviceGrid &d, int c, const int32_t *nodes, int32_t coun
                             d.gls_scratch_stride, d.gls_scratch_slots, stream);
 }
 
+// every GLS kernel of the launch plan but the cube-node kernel, all their nodes (the work counters are zeroed by the caller)
+static int launch_gls_but_cube(DeviceGrid &d, int add_neumann, double *out, double *nws, hipStream_t stream) {
+    int rc = 0;
+    for (int i = 0; i < 3 && !rc; ++i) rc = launch_mfw(d, d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, i, add_neumann, out, nws, stream);
+    for (int i = 0; i < 3 && !rc; ++i) rc = launch_gls_small(d.v, d.small[i].nodes, d.small[i].count, i, add_neumann, out, nws, stream);
+    if (!rc) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, out, nws, stream);
+    for (int c = 0; c < kGlsClasses && !rc; ++c) rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, out, nws, stream);
+    return rc;
+}
+
 int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t n_targets, int add_neumann,
                        double *dev_csr_data, double *dev_neumann_ws, void *stream_) {
     if (!g || !dev_csr_data || !dev_neumann_ws) return fail(NIN_EINVAL, "NULL argument");
@@ -647,14 +668,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else {
             HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
             rc = launch_hex8(d, d.hex8.nodes, d.hex8_desc, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
-            for (int i = 0; i < 3 && !rc; ++i)
-                rc = launch_mfw(d, d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, i, add_neumann, dev_csr_data, dev_neumann_ws, stream);
-            for (int i = 0; i < 3 && !rc; ++i)
-                rc = launch_gls_small(d.v, d.small[i].nodes, d.small[i].count, i, add_neumann, dev_csr_data, dev_neumann_ws, stream);
-            if (!rc) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
-            for (int c = 0; c < kGlsClasses && !rc; ++c) {
-                rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
-            }
+            if (!rc) rc = launch_gls_but_cube(d, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         }
         if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         return NIN_OK;
@@ -1028,6 +1042,21 @@ int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t
     if (!d.apply_weights) {   // the weights of the last apply: one buffer per grid, allocated on first use
         int rc = dev_alloc(d, &d.apply_weights, (size_t)std::max<int64_t>(d.nnz_e, 1));
         if (rc) return rc;
+    }
+    // GLS on a mesh with cube nodes: the cube-node kernel forms W . u itself (the 64 bytes of a node's row are neither written
+    // nor read again); the other kernels write their rows as always and a list kernel applies those (NIN_APPLY_NO_FUSION: off)
+    if (method == NIN_METHOD_GLS && d.hex8.count > 0 && d.noncube_nodes_ready && getenv("NIN_APPLY_NO_FUSION") == nullptr &&
+        getenv("NIN_HEX8_ONE_WAVE") == nullptr) {
+        if (!d.fields_set) return fail(NIN_ESTATE, "nin_fields_set has not been called");
+        if (!d.have_perm) return fail(NIN_ESTATE, "GLS needs permeability and diff_mag");
+        if (d.gls_too_large) return fail(NIN_ERANGE, "a node's GLS system has more than 1024 rows: beyond the fallback kernel");
+        HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));
+        int rc = launch_gls_hex8mf_apply(d.v, d.hex8.nodes, d.hex8_desc, d.hex8.count, 1, dev_u_cells, n_fields, dev_node_values,
+                                         dev_neumann_ws, d.gls_queue, stream);
+        if (!rc) rc = launch_gls_but_cube(d, 1, d.apply_weights, dev_neumann_ws, stream);
+        if (!rc) rc = launch_apply_list(d.v, d.apply_weights, dev_u_cells, n_fields, dev_node_values, d.noncube_nodes, d.noncube_count, stream);
+        if (rc) return fail(rc, "launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return NIN_OK;
     }
     // the weights are computed ONCE, whatever the number of fields (they depend on the mesh, the permeability and the
     // Neumann flags only: the reference's callers do `weights.dot(u)` per field with the same matrix)

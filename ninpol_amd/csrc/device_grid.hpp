@@ -83,6 +83,9 @@ struct DeviceGrid {
     int32_t *hex8_desc = nullptr;   // [4 * hex8.count] lane descriptors (hex8_desc.hpp)
     GlsClass mfw[3];   // kernels_gls_mfw.hip (mfw_desc.hpp): two-coloured nodes large (Kuhn tetrahedra) / small (wedges), general kind
     uint32_t *mfw_desc[3] = {nullptr, nullptr, nullptr};   // [kMfwDescWords * mfw[i].count] descriptor words
+    const int32_t *noncube_nodes = nullptr;   // every node the cube-node kernel does not take (the fused apply's list kernel)
+    int32_t noncube_count = 0;
+    bool noncube_nodes_ready = false;
     GlsClass quad4;      // kernels_gls_quad4.hip: nodes inside a boundary face of a hexahedron mesh (4 cells, 4 + 4 faces)
     int32_t *quad4_desc = nullptr;   // [2 * quad4.count] descriptor words
     GlsClass small[3];   // kernels_gls_mfw.hip, nin_gls_small_kernel: nodes with at most 4 / 8 / 12 cells and 64 rows that no kernel above takes

@@ -120,6 +120,22 @@ __global__ __launch_bounds__(256) void nin_apply_kernel(GridView g, const double
     }
 }
 
+// the listed nodes only: one lane per node, its row straight from HBM, every field in turn (sums in row order)
+__global__ __launch_bounds__(256) void nin_apply_list_kernel(GridView g, const double *__restrict__ data, const double *__restrict__ u,
+                                                             int32_t k, double *__restrict__ values, const int32_t *__restrict__ list,
+                                                             int32_t count) {
+    const size_t E = (size_t)g.n_elems, P = (size_t)g.n_points;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t p = list[i];
+        const int32_t b = g.esup_ptr[p], e = g.esup_ptr[p + 1];
+        for (int32_t f = 0; f < k; ++f) {
+            double acc = 0.0;
+            for (int32_t q = b; q < e; ++q) acc += data[q] * u[(size_t)f * E + (size_t)g.esup[q]];
+            values[(size_t)f * P + p] = acc;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nin_pad_centroids_kernel(const double *__restrict__ src, int64_t n, double *__restrict__ dst) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         dst[4 * e + 0] = src[3 * e + 0]; dst[4 * e + 1] = src[3 * e + 1]; dst[4 * e + 2] = src[3 * e + 2]; dst[4 * e + 3] = 0.0;
@@ -153,6 +169,13 @@ int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr
 int launch_pad_centroids(const double *src, int64_t n_elems, double *dst, hipStream_t stream) {
     if (n_elems <= 0) return 0;
     hipLaunchKernelGGL(nin_pad_centroids_kernel, dim3(grid_for(n_elems)), dim3(256), 0, stream, src, n_elems, dst);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_apply_list(const GridView &g, const double *data, const double *u, int32_t k, double *values, const int32_t *list,
+                      int32_t count, hipStream_t stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(nin_apply_list_kernel, dim3(grid_for(count)), dim3(256), 0, stream, g, data, u, k, values, list, count);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -613,10 +613,15 @@ __device__ __forceinline__ void w2_stage_c(const GridView &g, uint32_t eb, uint3
 #ifdef NIN_W2_TRACE
 __device__ unsigned long long nin_w2_trace[4096 * 4];   // per wave: start, end (s_memrealtime, 100 MHz), HW_ID, passes
 #endif
+// APPLY: instead of the weights, the node values W . u of `n_fields` cell fields (u: [n_fields][n_elems], values:
+// [n_fields][n_points]) -- the 64 bytes of a node's row are never written, nor read again by an apply kernel
+template <bool APPLY>
 __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                                 const int32_t *__restrict__ desc, int32_t count,
                                                                 int add_neumann, double *__restrict__ out,
-                                                                double *__restrict__ nws, int32_t *__restrict__ queue) {
+                                                                double *__restrict__ nws, int32_t *__restrict__ queue,
+                                                                const double *__restrict__ u_cells, int32_t n_fields,
+                                                                double *__restrict__ values) {
     __shared__ double lds_all[4][W2_WAVE_DOUBLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l = lane & 3, nd = lane >> 2;
@@ -878,7 +883,16 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
         const double nwv = is_neu ? wbuf[nd * 8 + 7] : 0.0;      // gls.pyx:470-472
         const double addv = add_neumann ? nwv : 0.0;
         const double o0 = wbuf[nd * 8 + 2 * l] + addv, o1 = wbuf[nd * 8 + 2 * l + 1] + addv;
-        if (valid) {
+        if (APPLY) {
+            // this lane's two entries of the row (esup order) times u, summed over the quad: one value per node and field
+            const size_t c0 = (size_t)g.esup[eb + 2 * l], c1 = (size_t)g.esup[eb + 2 * l + 1];
+            for (int32_t f = 0; f < n_fields; ++f) {
+                const double *uf = u_cells + (size_t)f * (size_t)g.n_elems;
+                const double yv = quad_sum(fma(o1, uf[c1], o0 * uf[c0]));
+                if (valid && l == 0) values[(size_t)f * (size_t)g.n_points + p] = yv;
+            }
+            if (valid && l == 0) nws[p] = nwv;
+        } else if (valid) {
             out[eb + 2 * l] = o0;
             out[eb + 2 * l + 1] = o1;
             if (l == 0) nws[p] = nwv;
@@ -932,10 +946,11 @@ int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *de
         if (blocks > 8) blocks &= ~(int64_t)7;
         if (getenv("NIN_DEBUG_OCCUPANCY") != nullptr) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nin_gls_hex8w2_kernel, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nin_gls_hex8w2_kernel<false>, 256, 0);
             fprintf(stderr, "nin_gls_hex8w2_kernel: %d workgroups per CU, %lld launched\n", nb, (long long)blocks);
         }
-        hipLaunchKernelGGL(nin_gls_hex8w2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count, add_neumann, out, nws, queue);
+        hipLaunchKernelGGL(nin_gls_hex8w2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count, add_neumann, out, nws, queue,
+                           nullptr, 0, nullptr);
 #ifdef NIN_W2_TRACE
         if (getenv("NIN_W2_TRACE_FILE") != nullptr) {
             static int calls = 0;
@@ -958,6 +973,18 @@ int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *de
     if (blocks > 8) blocks &= ~(int64_t)7;
     hipLaunchKernelGGL(nin_gls_hex8mf_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count,
                        add_neumann, out, nws, queue);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// the two-wave kernel in its apply form: values[f][p] = (W . u_f)[p] for the listed cube nodes, neumann_ws as always
+int launch_gls_hex8mf_apply(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
+                            const double *u_cells, int32_t n_fields, double *values, double *nws, int32_t *queue, hipStream_t stream) {
+    if (count <= 0) return 0;
+    int64_t blocks = ((int64_t)count + 4 * NPW - 1) / (4 * NPW);
+    if (blocks > 512) blocks = 512;
+    if (blocks > 8) blocks &= ~(int64_t)7;
+    hipLaunchKernelGGL(nin_gls_hex8w2_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count, add_neumann,
+                       nullptr, nws, queue, u_cells, n_fields, values);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -29,6 +29,8 @@ const char *kernel_name_gls_block();
 int launch_hex8_desc(const GridView &g, const int32_t *nodes, int32_t count, int32_t *desc, hipStream_t stream);
 int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
                       double *out, double *nws, int32_t *queue, hipStream_t stream);
+int launch_gls_hex8mf_apply(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
+                            const double *u_cells, int32_t n_fields, double *values, double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_hex8mf();
 // the one-wavefront multifrontal kernel for two-coloured nodes (kernels_gls_mfw.hip); `desc` = kMfwDescWords (40) descriptor words per
 // list entry (mfw_desc.hpp, filled by launch_mfw_desc); `queue`: one zeroed device int (the work counter)
@@ -58,6 +60,9 @@ int launch_rows_range(const GridView &g, int method_ls, int32_t n_points, int32_
                       double *out, double *nws, hipStream_t stream);
 
 int launch_apply(const GridView &g, const double *data, const double *u, double *values, int32_t mx_row, hipStream_t stream);
+// the same for the listed nodes only (one lane per node, rows straight from HBM)
+int launch_apply_list(const GridView &g, const double *data, const double *u, int32_t k, double *values, const int32_t *list,
+                      int32_t count, hipStream_t stream);
 // k fields at once: u [k][n_elems], values [k][n_points]
 int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values, int32_t mx_row,
                         hipStream_t stream);

@@ -445,6 +445,39 @@ def test_gpu_apply_matches_oracle_matrix_product(oracle_lib):
         I.apply("u", "gls", values=np.zeros((2, 5)))
 
 
+def test_gpu_apply_fused_in_the_cube_kernel(oracle_lib, monkeypatch):
+    """GLS apply on a mesh with cube nodes: the cube-node kernel forms W . u itself (no row of weights is written for those
+    nodes), the other kernels' rows go through a list kernel.  Against the oracle's W . u, and against the unfused path
+    (NIN_APPLY_NO_FUSION: weights, then the apply kernel) to rounding; one field and three; a Neumann plane, so that the
+    fused nodes, the quad nodes and the small nodes all carry values."""
+    mesh = M.hex_mesh(17, 14, 11, jitter=0.15, seed=12)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(0, 1.0), seed=9)
+    o = oracle_lib.OracleInterpolator("port", threads=8)
+    o.load_mesh(mesh)
+    Wo, nwo = o.interpolate("u", "gls")
+    u = np.concatenate(mesh.cell_data["u"])
+    rng = np.random.default_rng(5)
+    fields = np.stack([u, np.cos(2.0 * u), rng.uniform(-1.0, 1.0, len(u))])
+    got = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("NIN_APPLY_NO_FUSION", "1")
+        I = _interp()
+        I.load_mesh(mesh_obj=mesh)
+        vals, nws = I.apply("u", "gls")
+        many, nws3 = I.apply("u", "gls", values=fields)
+        assert I.grid.gls_plan()["hex8"] == 16 * 13 * 10
+        assert util.rowscaled_err(nws, nwo) <= util.WEIGHT_RTOL
+        np.testing.assert_array_equal(nws3, nws)
+        np.testing.assert_array_equal(many[0], vals)
+        for k in range(3):
+            ref = Wo.dot(fields[k])
+            assert np.abs(many[k] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (fused, k)
+        got[fused] = (many, nws)
+    assert np.abs(got[True][0] - got[False][0]).max() <= 1e-13 * np.abs(got[False][0]).max()
+    np.testing.assert_array_equal(got[True][1], got[False][1])
+
+
 def _gls_degenerate_nodes(g, flag):
     """The nodes outside GLS's parity set, from the grid arrays alone (gls.pyx:165-182,266-267): computed (not a
     Dirichlet boundary node) but with no internal face at all (n_bface >= n_face: the reference leaves Mi empty) or
