@@ -43,7 +43,7 @@ acc = collections.defaultdict(list)
 for f in glob.glob(out + "/pmc[0-9]/**/*counter_collection.csv", recursive=True) + glob.glob(out + "/pmc_tet_*/p[0-9]/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        if k.startswith("nin_"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if k.startswith("nin_"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))   # (the apply form of the cube kernel, nin_gls_hex8w2_kernel<true>, is its own row)
 with open(out + "/pmc_summary.csv", "w", newline="") as f:
     w = csv.writer(f); w.writerow(["kernel", "counter", "dispatches", "average_per_dispatch"])
     for (k, c), v in sorted(acc.items(), key=lambda kv: (kv[0][1], kv[0][0])): w.writerow([k, c, len(v), round(sum(v) / len(v), 1)])
@@ -51,14 +51,14 @@ avg = {kc: sum(v) / len(v) for kc, v in acc.items()}
 def traffic(prefixes):   # bytes per launch: 2 x FETCH (gfx950 correction, MI355X_MICROARCH.md) + WRITE, KiB units
     t = 0.0
     for (k, c), v in avg.items():
-        if any(k.startswith(p) for p in prefixes): t += v * 1024 * (2 if c == "FETCH_SIZE" else 1 if c == "WRITE_SIZE" else 0)
+        if any(k.startswith(p) for p in prefixes) and "<true>" not in k: t += v * 1024 * (2 if c == "FETCH_SIZE" else 1 if c == "WRITE_SIZE" else 0)   # (<true>: the apply leg, not the weights step)
     return int(t)
 sys.path.insert(0, os.getcwd())
 import bench
 def traffic_lo(prefixes):   # the same with FETCH_SIZE taken as it reads: the lower bound when the reads are scattered gathers
     t = 0.0
     for (k, c), v in avg.items():
-        if any(k.startswith(p) for p in prefixes): t += v * 1024 * (1 if c in ("FETCH_SIZE", "WRITE_SIZE") else 0)
+        if any(k.startswith(p) for p in prefixes) and "<true>" not in k: t += v * 1024 * (1 if c in ("FETCH_SIZE", "WRITE_SIZE") else 0)
     return int(t)
 tj = {"kernel_source_sha16": bench.kernel_source_hash(),
       "note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section: gfx950 tallies 128-B requests at 64 B). That rule is calibrated for coalesced streams; tools/micro_fetch.hip (profiles/r03/micro_fetch.txt) confirms it for 4 / 8 / 16 B per lane and shows that scattered gathers read anywhere between 0.5 and 2.3 of the bytes they use, so for the GLS kernels (4-16 B gathers) the doubled figure is the guide's prescription and *_bounds = [FETCH as read + WRITE, 2 FETCH + WRITE] brackets it. pmc_summary.csv of the round holds the raw counters.",
