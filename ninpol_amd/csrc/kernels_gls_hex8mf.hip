@@ -988,6 +988,7 @@ int launch_gls_hex8mf_apply(const GridView &g, const int32_t *nodes, const int32
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-const char *kernel_name_gls_hex8mf() { return getenv("NIN_HEX8_ONE_WAVE") == nullptr ? "nin_gls_hex8w2_kernel" : "nin_gls_hex8mf_kernel"; }
+// (as rocprofv3 prints it: the weights form of the two-wave kernel is the instantiation <false>, the apply form <true>)
+const char *kernel_name_gls_hex8mf() { return getenv("NIN_HEX8_ONE_WAVE") == nullptr ? "nin_gls_hex8w2_kernel<false>" : "nin_gls_hex8mf_kernel"; }
 
 }  // namespace nin
