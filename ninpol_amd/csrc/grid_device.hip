@@ -573,7 +573,10 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
             node_class[p] = (F <= kMfwSmallFronts && D <= kMfwSmallDense) ? 253 : 254;
             return;
         }
-        if (kind == 2 && (use_group & 4)) { node_class[p] = 252; return; }
+        // (general-kind nodes that fit the small-node kernel -- pyramid apexes: 7 cells, 43 rows -- are cheaper there: 26.64 -> 26.54 ms
+        //  on BASELINE config [3])
+        const bool small_fits = (use_group & 8) && !force_global && g.dim == 3 && ne <= 12 && nf <= 48 && ne + 3 * nf <= 64;
+        if (kind == 2 && (use_group & 4) && !small_fits) { node_class[p] = 252; return; }
     }
     // nodes inside a boundary face of a hexahedron mesh: two lanes per node (kernels_gls_quad4.hip)
     if ((use_group & 16) && !force_global && ne == 4 && nf == 8 && nbf == 4 && g.dim == 3) {
