@@ -207,6 +207,57 @@ def mixed_mesh(nx, ny=None, nz=None, n_hex=None, lengths=(1.0, 1.0, 1.0), jitter
                       CellBlock("tetra", tets)])
 
 
+def delaunay_tet_mesh(n, jitter=0.25, seed=0, lattice="bcc", renumber=True):
+    """UNSTRUCTURED tetrahedra: the Delaunay tetrahedrisation (scipy.spatial.Delaunay = Qhull) of a jittered point cloud
+    in the unit box -- the mesh class the reference's tetra / prism / misc numbers are taken on (gmsh-type meshes,
+    tests/results/yaml/performance.yaml:184-246: ~23 cells per node); the reference ships no mesh files, so this generator
+    stands in for them.  Node degree is irregular: 2 V - 4 cells around an interior node with V neighbours -- 14 .. 40, mean 25
+    for the default cloud (Kuhn meshes: always 24; no two-colouring of the cells either).
+
+    lattice = "bcc": the corners and the centres of an n^3 lattice (2 n^3 + ... points, ~12.5 n^3 cells), each moved by
+              U(-jitter, jitter) * h -- slivers stay rare (smallest cell volume ~1e-3 h^3 at jitter 0.25);
+              "random": the lattice corners on the boundary + (n - 1)^3 + n^3 uniform random interior points (a wider degree
+              distribution: up to ~50 cells per node, and worse cells).
+    Boundary points stay in their boundary plane (corners fixed), so the hull is the box.  renumber: nodes in (z, y, x) order of
+    their lattice cell and cells in the order of their lowest node, so that contiguous node blocks are z-slabs as in the
+    structured generators (Qhull's own order is kept otherwise)."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    h = 1.0 / n
+    g = np.arange(n + 1) * h
+    Z, Y, X = np.meshgrid(g, g, g, indexing="ij")
+    corners = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    c = (np.arange(n) + 0.5) * h
+    Z, Y, X = np.meshgrid(c, c, c, indexing="ij")
+    centres = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    if lattice == "bcc":
+        pts = np.vstack([corners, centres])
+        d = rng.uniform(-jitter, jitter, size=pts.shape) * h
+    elif lattice == "random":
+        on_b = np.any((corners < 1e-12) | (corners > 1 - 1e-12), axis=1)
+        n_int = (n - 1) ** 3 + n ** 3
+        pts = np.vstack([corners[on_b], rng.uniform(0.2 * h, 1.0 - 0.2 * h, size=(n_int, 3))])
+        d = np.zeros_like(pts)
+        d[:int(on_b.sum())] = rng.uniform(-jitter, jitter, size=(int(on_b.sum()), 3)) * h
+    else:
+        raise ValueError("lattice must be 'bcc' or 'random'")
+    for a in range(3):                                   # boundary points only move inside their boundary plane
+        on = (np.abs(pts[:, a]) < 1e-12) | (np.abs(pts[:, a] - 1.0) < 1e-12)
+        d[on, a] = 0.0
+    pts = pts + d
+    tets = Delaunay(pts).simplices.astype(np.int64)
+    if renumber:
+        ijk = np.clip(np.floor(pts / h - 1e-9).astype(np.int64), 0, n - 1)
+        order = np.lexsort((pts[:, 0], ijk[:, 0], ijk[:, 1], ijk[:, 2]))
+        new_id = np.empty(len(pts), dtype=np.int64)
+        new_id[order] = np.arange(len(pts))
+        pts = pts[order]
+        tets = new_id[tets]
+        tets = tets[np.lexsort((tets.max(axis=1), tets.min(axis=1)))]
+    tets = _fix_tet_orientation(pts, tets)
+    return Mesh(np.ascontiguousarray(pts), [CellBlock("tetra", tets)])
+
+
 def quad_tri_mesh_2d(nx, ny=None, jitter=0.0, seed=0):
     """2-D mesh on the unit square: left half quads, right half triangles (each lattice cell cut along its
     0-2 diagonal).  Points are (P, 3) with z = 0, as meshio delivers 2-D meshes."""
