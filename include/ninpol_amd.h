@@ -195,9 +195,10 @@ const char *nin_kernel_name(int method);
  * counts[6], counts[7], counts[8]: the one-wavefront multifrontal kernel -- two-coloured nodes (large / small
  * instantiation) and the general kind, counts[9], counts[10], counts[11]: the one-wavefront dense kernel for small nodes
  * (at most 4 / 8 / 12 cells; in practice the boundary nodes that are computed), counts[12]: the two-lanes-per-node kernel for
- * the nodes inside a boundary face of a hexahedron mesh.  (Diagnostics and tests: the reference has one code path,
+ * the nodes inside a boundary face of a hexahedron mesh, counts[13]: the wide one-wavefront multifrontal kernel (interior nodes
+ * of unstructured meshes: up to 16 fronts + 21 dense cells).  (Diagnostics and tests: the reference has one code path,
  * gls.pyx:138-197, for every node.) */
-int nin_gls_plan(const nin_grid *g, int64_t counts[13]);
+int nin_gls_plan(const nin_grid *g, int64_t counts[14]);
 
 #ifdef __cplusplus
 }

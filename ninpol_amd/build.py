@@ -30,6 +30,7 @@ UNITS = [
     # the end of the pass (kernels_gls_hex8mf.hip, grab_issue / grab_value)
     ("kernels_gls_hex8mf.hip", "hipcc", ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]),
     ("kernels_gls_mfw.hip", "hipcc", []),
+    ("kernels_gls_mfx.hip", "hipcc", []),
     ("kernels_gls_quad4.hip", "hipcc", []),
     ("kernels_csr.hip", "hipcc", []),
     # device-side grid build: no contraction, like grid_host.cpp (float32 normals must match the reference)

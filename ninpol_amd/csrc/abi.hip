@@ -18,6 +18,7 @@
 #include "grid_host.hpp"
 #include "launch.hpp"
 #include "mfw_desc.hpp"
+#include "mfx_desc.hpp"
 
 using namespace nin;
 
@@ -456,12 +457,14 @@ int nin_grid_to_device(nin_grid *g, int device) {
     // ---- GLS launch plan: bin nodes by the size of their least-squares system (classified on the device) ----
     g->node_class.assign((size_t)P, 0);
     std::vector<std::vector<int32_t>> lists(kGlsClasses);
-    std::vector<int32_t> hex8_list, mfw_list[3], small_list[3], quad4_list;
+    std::vector<int32_t> hex8_list, mfw_list[3], small_list[3], quad4_list, mfx_list;
     // debugging switches: keep nodes away from the hex8 kernel (bit 0) / the one-wavefront multifrontal kernel (bit 1)
     const int use_group = (getenv("NIN_GLS_NO_GROUP") == nullptr ? 1 : 0) | (getenv("NIN_GLS_NO_MFW") == nullptr ? 2 : 0) |
                           (getenv("NIN_GLS_NO_MFW_GENERAL") == nullptr ? 4 : 0) |   // (bit 2: the multifrontal kernel's general kind)
                           (getenv("NIN_GLS_NO_SMALL") == nullptr ? 8 : 0) |         // (bit 3: the one-wavefront dense kernel for small nodes)
-                          (getenv("NIN_GLS_NO_QUAD4") == nullptr ? 16 : 0);         // (bit 4: the two-lanes-per-node kernel for quad nodes)
+                          (getenv("NIN_GLS_NO_QUAD4") == nullptr ? 16 : 0) |        // (bit 4: the two-lanes-per-node kernel for quad nodes)
+                          (getenv("NIN_GLS_NO_MFX") == nullptr ? 32 : 0) |          // (bit 5: the wide multifrontal kernel: unstructured meshes)
+                          (getenv("NIN_GLS_MFX_ALL") != nullptr ? 64 : 0);          // (bit 6: ... takes the general kind's nodes too)
     const bool force_global = getenv("NIN_GLS_FORCE_GLOBAL") != nullptr;   // testing switch: systems in global scratch
     int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0}, cols_max[kGlsClasses] = {0};
     {
@@ -486,6 +489,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         else if (c >= 252 && c <= 254) mfw_list[254 - c].push_back((int32_t)p);
         else if (c >= 249 && c <= 251) small_list[c - 249].push_back((int32_t)p);
         else if (c == 248) quad4_list.push_back((int32_t)p);
+        else if (c == 247) mfx_list.push_back((int32_t)p);
         else lists[c].push_back((int32_t)p);
     }
     for (int c = 0; c < kGlsClasses; ++c) {
@@ -541,6 +545,16 @@ int nin_grid_to_device(nin_grid *g, int device) {
             if (launch_mfw_desc(d.v, d.mfw[i].nodes, d.mfw[i].count, d.mfw_desc[i], nullptr)) return fail(NIN_EHIP, "mfw descriptor kernel");
         }
     }
+    {
+        d.mfx.count = (int32_t)mfx_list.size();
+        const int32_t *lp = nullptr;
+        if (d.mfx.count && (rc = dev_upload(d, &lp, mfx_list))) return rc;
+        d.mfx.nodes = const_cast<int32_t *>(lp);
+        if (d.mfx.count) {   // descriptors of the wide multifrontal kernel, kMfxDescWords (56) words per list entry
+            if ((rc = dev_alloc(d, &d.mfx_desc, (size_t)d.mfx.count * kMfxDescWords))) return rc;
+            if (launch_mfx_desc(d.v, d.mfx.nodes, d.mfx.count, d.mfx_desc, nullptr)) return fail(NIN_EHIP, "mfx descriptor kernel");
+        }
+    }
     for (int i = 0; i < 3; ++i) {
         d.small[i].count = (int32_t)small_list[i].size();
         const int32_t *lp = nullptr;
@@ -577,6 +591,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         for (int i = 0; i < 3; ++i) cut(kGlsClasses + 1 + i, mfw_list[i]);
         for (int i = 0; i < 3; ++i) cut(kGlsClasses + 4 + i, small_list[i]);
         cut(kGlsClasses + 7, quad4_list);
+        cut(kGlsClasses + 8, mfx_list);
         const char *mn = getenv("NIN_E2E_MIN_NODES");                                // (tests: the pipeline on small meshes too)
         d.chunkable = P >= (mn ? atoll(mn) : 64 * 1024) && P >= 64 * K && getenv("NIN_E2E_NO_PIPELINE") == nullptr;   // small meshes: one piece
     }
@@ -641,6 +656,7 @@ static int launch_gls_but_cube(DeviceGrid &d, int add_neumann, double *out, doub
     for (int i = 0; i < 3 && !rc; ++i) rc = launch_mfw(d, d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, i, add_neumann, out, nws, stream);
     for (int i = 0; i < 3 && !rc; ++i) rc = launch_gls_small(d.v, d.small[i].nodes, d.small[i].count, i, add_neumann, out, nws, stream);
     if (!rc) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, out, nws, stream);
+    if (!rc) rc = launch_gls_mfx(d.v, d.mfx.nodes, d.mfx_desc, d.mfx.count, add_neumann, out, nws, d.gls_queue + 8, stream);   // (work counter: int 8)
     for (int c = 0; c < kGlsClasses && !rc; ++c) rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, out, nws, stream);
     return rc;
 }
@@ -679,13 +695,14 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     HIP_TRY(hipMemsetAsync(dev_csr_data, 0, (size_t)d.nnz_e * 8, stream));
     HIP_TRY(hipMemsetAsync(dev_neumann_ws, 0, (size_t)P * 8, stream));
     if (n_targets == 0) return NIN_OK;
-    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 8 : 1);
+    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 9 : 1);
     for (int64_t i = 0; i < n_targets; ++i) {
         int c = method == NIN_METHOD_GLS ? g->node_class[targets[i]] : 0;
         if (c == 255) c = kGlsClasses;   // the hex8 kernel's class
         else if (c >= 252 && c <= 254) c = kGlsClasses + 1 + (254 - c);   // the one-wavefront multifrontal kernel, kind 0 / 1 / 2
         else if (c >= 249 && c <= 251) c = kGlsClasses + 4 + (c - 249);   // the small-node kernel, kind 0 / 1 / 2
         else if (c == 248) c = kGlsClasses + 7;                           // the quad-node kernel
+        else if (c == 247) c = kGlsClasses + 8;                           // the wide multifrontal kernel
         lists[c].push_back((int32_t)targets[i]);
     }
     // one device buffer for all class lists, filled before the first launch: a per-class allocate / copy / free
@@ -702,10 +719,12 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     const size_t n_hex8 = method == NIN_METHOD_GLS ? lists[kGlsClasses].size() : 0;   // + 4 descriptor words per cube node
     const size_t n_mfw = method == NIN_METHOD_GLS ? lists[kGlsClasses + 1].size() + lists[kGlsClasses + 2].size() + lists[kGlsClasses + 3].size() : 0;   // + kMfwDescWords per node of the multifrontal kernel (the three lists are adjacent)
     const size_t n_quad4 = method == NIN_METHOD_GLS ? lists[kGlsClasses + 7].size() : 0;   // + 2 descriptor words per quad node
-    HIP_TRY(hipMalloc((void **)&dl0, (flat.size() + 4 * n_hex8 + kMfwDescWords * n_mfw + 2 * n_quad4) * 4));
+    const size_t n_mfx = method == NIN_METHOD_GLS ? lists[kGlsClasses + 8].size() : 0;     // + kMfxDescWords per node of the wide multifrontal kernel
+    HIP_TRY(hipMalloc((void **)&dl0, (flat.size() + 4 * n_hex8 + kMfwDescWords * n_mfw + 2 * n_quad4 + kMfxDescWords * n_mfx) * 4));
     int32_t *ddesc = dl0 + flat.size();
     uint32_t *dmfw = reinterpret_cast<uint32_t *>(ddesc + 4 * n_hex8);
     int32_t *dquad = reinterpret_cast<int32_t *>(dmfw + kMfwDescWords * n_mfw);
+    uint32_t *dmfx = reinterpret_cast<uint32_t *>(dquad + 2 * n_quad4);
     const hipError_t cp = hipMemcpy(dl0, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
     if (cp != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemcpy: %s", hipGetErrorString(cp)); }
     if (n_hex8 && launch_hex8_desc(d.v, dl0 + first[kGlsClasses], (int32_t)n_hex8, ddesc, stream)) {
@@ -720,6 +739,10 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         (void)hipFree(dl0);
         return fail(NIN_EHIP, "quad4 descriptor kernel");
     }
+    if (n_mfx && launch_mfx_desc(d.v, dl0 + first[kGlsClasses + 8], (int32_t)n_mfx, dmfx, stream)) {
+        (void)hipFree(dl0);
+        return fail(NIN_EHIP, "mfx descriptor kernel");
+    }
     if (method == NIN_METHOD_GLS) {
         const hipError_t qe = hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream);
         if (qe != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemsetAsync: %s", hipGetErrorString(qe)); }
@@ -731,6 +754,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_hex8(d, dl, ddesc, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
+        else if ((int)c == kGlsClasses + 8) rc = launch_gls_mfx(d.v, dl, dmfx, cnt, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue + 8, stream);
         else if ((int)c == kGlsClasses + 7) rc = launch_gls_quad4(d.v, dl, dquad, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c >= kGlsClasses + 4) rc = launch_gls_small(d.v, dl, cnt, (int)c - kGlsClasses - 4, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c > kGlsClasses)
@@ -885,6 +909,10 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
     if (!rc) {
         const int32_t b = d.chunk_off[kGlsClasses + 7][k], n = d.chunk_off[kGlsClasses + 7][k + 1] - b;
         if (n > 0) rc = launch_gls_quad4(d.v, d.quad4.nodes + b, d.quad4_desc + 2 * (size_t)b, n, 1, out, nws, stream);
+    }
+    if (!rc) {
+        const int32_t b = d.chunk_off[kGlsClasses + 8][k], n = d.chunk_off[kGlsClasses + 8][k + 1] - b;
+        if (n > 0) rc = launch_gls_mfx(d.v, d.mfx.nodes + b, d.mfx_desc + (size_t)kMfxDescWords * b, n, 1, out, nws, d.gls_queue + 8, stream);
     }
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         const int32_t b = d.chunk_off[c][k], n = d.chunk_off[c][k + 1] - b;
@@ -1129,7 +1157,7 @@ int nin_host_free(void *ptr) {
     return NIN_OK;
 }
 
-int nin_gls_plan(const nin_grid *g, int64_t counts[13]) {
+int nin_gls_plan(const nin_grid *g, int64_t counts[14]) {
     if (!g || !counts) return fail(NIN_EINVAL, "NULL argument");
     if (g->d.device < 0 || g->d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
     for (int c = 0; c < kGlsClasses; ++c) counts[c] = g->d.gls[c].count;
@@ -1139,6 +1167,7 @@ int nin_gls_plan(const nin_grid *g, int64_t counts[13]) {
     counts[8] = g->d.mfw[2].count;
     for (int i = 0; i < 3; ++i) counts[9 + i] = g->d.small[i].count;
     counts[12] = g->d.quad4.count;
+    counts[13] = g->d.mfx.count;
     return NIN_OK;
 }
 

@@ -29,6 +29,7 @@
 #include "hex8_desc.hpp"
 #include "quad4_desc.hpp"
 #include "mfw_desc.hpp"
+#include "mfx_desc.hpp"
 #include "launch.hpp"
 
 namespace nin {
@@ -576,7 +577,13 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
         // (general-kind nodes that fit the small-node kernel -- pyramid apexes: 7 cells, 43 rows -- are cheaper there: 26.64 -> 26.54 ms
         //  on BASELINE config [3])
         const bool small_fits = (use_group & 8) && !force_global && g.dim == 3 && ne <= 12 && nf <= 48 && ne + 3 * nf <= 64;
-        if (kind == 2 && (use_group & 4) && !small_fits) { node_class[p] = 252; return; }
+        // (bit 6: the wide kernel takes the general kind's nodes too -- A/B switch)
+        if (kind == 2 && (use_group & 4) && !small_fits && !(use_group & 64)) { node_class[p] = 252; return; }
+    }
+    // interior nodes of unstructured meshes: more cells than the kinds above hold (kernels_gls_mfx.hip, mfx_desc.hpp)
+    if ((use_group & 32) && !force_global && nbf == 0 && ne <= kMfxMaxCells && ne > 12) {
+        uint32_t w[kMfxDescWords];
+        if (mfx_descriptor(g, (int32_t)p, w)) { node_class[p] = 247; return; }
     }
     // nodes inside a boundary face of a hexahedron mesh: two lanes per node (kernels_gls_quad4.hip)
     if ((use_group & 16) && !force_global && ne == 4 && nf == 8 && nbf == 4 && g.dim == 3) {

@@ -1,0 +1,347 @@
+// kernels_gls_mfx.hip -- GLS weights of interior nodes of UNSTRUCTURED meshes (mfx_desc.hpp: up to 16 fronts + 21 dense cells,
+// 16 free faces; a Delaunay tetrahedrisation has 14 .. 40 cells around a node), gfx950: one wavefront per node, ONE wavefront per
+// SIMD -- the dense problem, up to 160 x 64, lives in 160 16-row x 4-column tiles of the unified register file (the matrix unit
+// reads and writes the accumulation registers directly, so the tiles never pass through the vector registers).
+//
+// The system and phase 1 are kernels_gls_mfw.hip's (gls.pyx:252-356; fronts = cells with exactly 3 faces at the node that share
+// no face, four lanes per front).  What differs is the dense phase.  kernels_gls_mfw.hip's strip form unrolls one body per
+// generation of panels and per node size class (its 96 x 37 Kuhn problem: 5 bodies, 60 tiles, two wavefronts per SIMD); at
+// 160 x 64 that would be 8 bodies of ~60 KB of code sweeping blocks of zeros for every node smaller than the largest.  Here ONE
+// body serves every panel of every node: which tiles and column blocks take part is decided by wave-uniform branches (the pivot
+// tile index, the number of live row tiles and of live trailing column blocks are scalars), so the work is proportional to the
+// node's own size -- a 96 x 37 node executes what the Kuhn instantiation executes -- and the code stays inside the instruction
+// cache.  Same mathematics as dgels on the reference's matrix: a blocked Householder QR (compact WY, panels of four) under a
+// column / row order that exposes the zeros.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "device_grid.hpp"
+#include "gls_device_math.hpp"
+#include "launch.hpp"
+#include "mfw_strips.hpp"
+#include "mfx_desc.hpp"
+#include "mfx_strips.hpp"
+
+namespace nin {
+
+namespace {
+
+using namespace glsmath;
+using namespace mfwstrips;
+using namespace mfxstrips;
+
+// Staging area (phase 1 -> tiles; it lies under R): every row of the dense problem as 13 doubles
+//     [0 0 0 | cell 1 (3) | cell 2 (3) | cell 3 (3) | c]
+// so that the entry of a column whose cell has code k in the row (0: not one of the row's cells) is at 3 k + component -- code 0
+// reads the zeros in front, no select.  A front's 7 fill rows have 3 cells, a free face's 3 rows 2, a dense cell's row 1 (c = 1).
+constexpr int XROW = 13, XSTAGE_F = 7 * XROW, XSTAGE_Q = 3 * XROW;
+constexpr int XNP = 3 * kMfxMaxDense;                // pivot rows
+constexpr int X_CD = kMfxMaxFronts * XSTAGE_F;       // the dense cells' rows
+constexpr int X_FS = X_CD + kMfxMaxDense * XROW;     // the free faces' rows
+constexpr int X_Y = XNP * XRP + 1, X_W = X_Y + 64, X_Z = X_W + 40, X_DESC = X_Z + 2,
+              X_PER_WAVE = X_DESC + kMfxDescWords / 2;
+static_assert(X_FS + kMfxMaxFree * XSTAGE_Q <= XNP * XRP, "the staging area lies under R");
+static_assert(16 * XQ >= kMfxMaxRows && 4 * XCB >= XNP + 1 && (X_DESC & 1) == 0, "tiles");
+
+__global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32_t *__restrict__ nodes, const uint32_t *__restrict__ desc,
+                                                        int32_t count, int add_neumann, double *__restrict__ out,
+                                                        double *__restrict__ nws, int32_t *__restrict__ queue) {
+    __shared__ double Rm[X_PER_WAVE];
+    const int lane = threadIdx.x;
+    double *const yb = Rm + X_Y, *const wbuf = Rm + X_W;
+    uint32_t *const dl = reinterpret_cast<uint32_t *>(Rm + X_DESC);
+    const uint8_t *const slotpos = reinterpret_cast<const uint8_t *>(dl + kMfxSlotTable);
+    if (lane == 0) { Rm[X_Z] = 0.0; Rm[X_Z + 1] = 1.0; }
+    const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
+
+    auto ticket = [&]() -> int32_t {
+        int32_t v = 0;
+        if (lane == 0) v = atomicAdd(queue, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    for (int32_t idx = ticket(); idx < count; idx = ticket()) {
+        const int32_t p = __builtin_amdgcn_readfirstlane(nodes ? nodes[idx] : idx);
+        const uint32_t *dw = desc + (size_t)kMfxDescWords * idx;
+        if (lane < kMfxDescWords) dl[lane] = dw[lane];
+        const uint32_t fd = (uint32_t)__builtin_amdgcn_readfirstlane((int)dw[0]);
+        const int F = fd & 255, D = (fd >> 8) & 255, nfree = (fd >> 16) & 255, ne = F + D;
+        const uint32_t eb = (uint32_t)__builtin_amdgcn_readfirstlane(g.esup_ptr[p]);
+        const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane(g.fsup_ptr[p]);
+        const bool is_neu = (__builtin_amdgcn_readfirstlane((int)g.flags[p]) & 2) != 0;
+        const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1], xv2 = g.coords[3 * (size_t)p + 2];
+        wave_lds_sync();
+        // phase 1 works with FOUR lanes per front: lane 4 f + j applies the front's reflectors to c (j = 0) or to the columns of
+        // the front's neighbour j - 1; dense cell d's centroid is fetched by lane d
+        const int fq = lane >> 2, jq = lane & 3;
+        const uint32_t wa = dl[kMfxW0 + fq], wb = dl[kMfxW1 + fq];
+        const uint32_t pe = wa & 63u;
+        const uint32_t po = slotpos[lane < kMfxMaxDense ? lane : 0];
+        const int my = jq > 0 ? jq - 1 : 0;                      // this lane's face (the c lane computes face 0's neighbour side in vain)
+        const uint32_t myslot = (wb >> (5 * my)) & 31u;
+        // ---- phase 1: the front of cell E_f (rows 0 = cell row, 1 + 3 i + r = row r of face i) ------------------------------
+        // u: this lane's block of u = z^T R_ed (3 columns), or s = z . b_e in u[0] of the c lane
+        double u[3], de[3], dod[3];
+        {
+            const uint32_t ce = (uint32_t)g.esup[eb + pe], co = (uint32_t)g.esup[eb + po];
+            const uint32_t cm = (uint32_t)g.esup[eb + slotpos[myslot]];
+            double P[10][3], B[10][3];
+            double Ke[9], Km[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { Ke[k] = g.perm[9 * (size_t)ce + k]; Km[k] = g.perm[9 * (size_t)cm + k]; }
+            const double dme = g.diff_mag[ce];
+            de[0] = g.centroids[3 * (size_t)ce + 0] - xv0;      // gls.pyx:269-277
+            de[1] = g.centroids[3 * (size_t)ce + 1] - xv1;
+            de[2] = g.centroids[3 * (size_t)ce + 2] - xv2;
+            dod[0] = g.centroids[3 * (size_t)co + 0] - xv0;
+            dod[1] = g.centroids[3 * (size_t)co + 1] - xv1;
+            dod[2] = g.centroids[3 * (size_t)co + 2] - xv2;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { P[0][t] = de[t]; B[0][t] = (jq == 0 && t == 0) ? 1.0 : 0.0; }   // c = e_0 on entry
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                // B = [K N; T1; tau T2] (gls.pyx:293-321), row = [-B_a | +B_b] (gls.pyx:340-356)
+                const uint32_t f = (uint32_t)g.fsup[fb + ((wa >> (6 + 6 * i)) & 63u)];
+                const uint32_t cn = (uint32_t)g.esup[eb + slotpos[(wb >> (5 * i)) & 31u]];
+                const double N0 = (double)g.face_normal[3 * (size_t)f + 0], N1 = (double)g.face_normal[3 * (size_t)f + 1],
+                             N2 = (double)g.face_normal[3 * (size_t)f + 2];
+                const double T0 = xv0 - g.face_center[3 * (size_t)f + 0], T1 = xv1 - g.face_center[3 * (size_t)f + 1],
+                             T2 = xv2 - g.face_center[3 * (size_t)f + 2];
+                const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+                const double dmn = g.diff_mag[cn];
+                double eta = 0.0;
+                eta = dme > eta ? dme : eta;
+                eta = dmn > eta ? dmn : eta;
+                const double tj = face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
+                const double sg = ((wa >> (24 + i)) & 1u) ? -1.0 : 1.0;
+                const bool mine = jq > 0 && my == i;
+                const double s0[3] = {sg * T0, sg * T1, sg * T2}, s1[3] = {sg * (tj * U0), sg * (tj * U1), sg * (tj * U2)};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    P[1 + 3 * i][t] = sg * (Ke[t * 3 + 0] * N0 + Ke[t * 3 + 1] * N1 + Ke[t * 3 + 2] * N2);
+                    P[2 + 3 * i][t] = s0[t];
+                    P[3 + 3 * i][t] = s1[t];
+                    // the neighbour's side of the face rows, in the lane that owns this face only (zero elsewhere)
+                    const double nb = -sg * (Km[t * 3 + 0] * N0 + Km[t * 3 + 1] * N1 + Km[t * 3 + 2] * N2);
+                    B[1 + 3 * i][t] = mine ? nb : 0.0;
+                    B[2 + 3 * i][t] = mine ? -s0[t] : 0.0;
+                    B[3 + 3 * i][t] = mine ? -s1[t] : 0.0;
+                }
+            }
+            // panel: three Householder steps on the own columns; v_k stays in P[k..9][k]; z = R_ee^-T d_e
+            double g3[3], z[3];
+            front_panel(P, de, g3, z);
+            // the reflectors on this lane's block; rows 0..2 -> u (or s); rows 3..9 -> the staging area
+            __builtin_amdgcn_sched_barrier(0);
+            apply_panel<3, true, true, true, true>(P, g3, B);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) u[t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));
+            if (fq < F) {
+                // the c lane writes c and the row's three zeros, the others their cell's three entries
+                double *stg = Rm + fq * XSTAGE_F + (jq == 0 ? 0 : 3 + 3 * my);
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    stg[r * XROW + 0] = jq == 0 ? 0.0 : B[3 + r][0];
+                    stg[r * XROW + 1] = jq == 0 ? 0.0 : B[3 + r][1];
+                    stg[r * XROW + 2] = jq == 0 ? 0.0 : B[3 + r][2];
+                }
+                if (jq == 0) {
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) stg[r * XROW + 12] = B[3 + r][0];
+                }
+            }
+        }
+        if (lane < nfree) {
+            // a free face (both its cells dense): its three rows [-B_a | +B_b] (gls.pyx:293-356) go straight into the dense problem
+            const uint32_t fw = dl[kMfxFree0 + lane];
+            const uint32_t f = (uint32_t)g.fsup[fb + (fw & 63u)];
+            const uint32_t ca_ = (uint32_t)g.esup[eb + slotpos[(fw >> 6) & 31u]], cb_ = (uint32_t)g.esup[eb + slotpos[(fw >> 11) & 31u]];
+            const double N0 = (double)g.face_normal[3 * (size_t)f + 0], N1 = (double)g.face_normal[3 * (size_t)f + 1],
+                         N2 = (double)g.face_normal[3 * (size_t)f + 2];
+            const double T0 = xv0 - g.face_center[3 * (size_t)f + 0], T1 = xv1 - g.face_center[3 * (size_t)f + 1],
+                         T2 = xv2 - g.face_center[3 * (size_t)f + 2];
+            const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+            const double da = g.diff_mag[ca_], db = g.diff_mag[cb_];
+            double eta = 0.0;
+            eta = da > eta ? da : eta;
+            eta = db > eta ? db : eta;
+            const double tj = face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
+            const double *Ka = g.perm + 9 * (size_t)ca_, *Kb = g.perm + 9 * (size_t)cb_;
+            double *fs = Rm + X_FS + XSTAGE_Q * lane;
+            const double Tv[3] = {T0, T1, T2}, Uv[3] = {tj * U0, tj * U1, tj * U2};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                fs[0 * XROW + t] = 0.0; fs[1 * XROW + t] = 0.0; fs[2 * XROW + t] = 0.0;
+                fs[0 * XROW + 3 + t] = -(Ka[t * 3 + 0] * N0 + Ka[t * 3 + 1] * N1 + Ka[t * 3 + 2] * N2);
+                fs[0 * XROW + 6 + t] = Kb[t * 3 + 0] * N0 + Kb[t * 3 + 1] * N1 + Kb[t * 3 + 2] * N2;
+                fs[1 * XROW + 3 + t] = -Tv[t];
+                fs[1 * XROW + 6 + t] = Tv[t];
+                fs[2 * XROW + 3 + t] = -Uv[t];
+                fs[2 * XROW + 6 + t] = Uv[t];
+            }
+            fs[0 * XROW + 12] = 0.0; fs[1 * XROW + 12] = 0.0; fs[2 * XROW + 12] = 0.0;
+        }
+        // the dense cells' rows: (x_K - x_v) on the cell's own columns, c = 1
+        if (lane < D) {
+            double *cd = Rm + X_CD + XROW * lane;
+            cd[0] = 0.0; cd[1] = 0.0; cd[2] = 0.0;
+            cd[3] = dod[0]; cd[4] = dod[1]; cd[5] = dod[2];
+            cd[12] = 1.0;
+        }
+        wave_lds_sync();
+
+        const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
+        const int nrows = 7 * F + D + 3 * nfree, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
+        double rr;
+        {
+            // ---- the dense problem in 16 x 4 tiles: rows = the fronts' 7 fill rows each, the D cell rows, 3 rows per free face --
+            double C[XQ][XCB];
+            // code(sd) = 1 + the index of dense slot sd among the row's cells (0: not one of them), two bits per slot; a front's
+            // table is made once (lane f) and shuffled
+            uint32_t tlo = 0u, thi = 0u;
+            {
+                const uint32_t wbl = dl[kMfxW1 + (lane < kMfxMaxFronts ? lane : 0)];
+                const uint64_t t = (1ull << (2 * (wbl & 31u))) | (2ull << (2 * ((wbl >> 5) & 31u))) | (3ull << (2 * ((wbl >> 10) & 31u)));
+                tlo = lane < F ? (uint32_t)t : 0u;
+                thi = lane < F ? (uint32_t)(t >> 32) : 0u;
+            }
+            // per tile row q, this lane's row: rtl / rth = the 2-bit codes of its cells' slots (slots 0 .. 15 / 16 .. 20), rbz = the
+            // byte address of the row in the staging area (the lanes of rows that do not exist read front 0's zeros), rbc = of its c
+            uint32_t rtl[XQ], rth[XQ], rbz[XQ], rbc[XQ];
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) {
+                const int row = 16 * q + 4 * sb + si;
+                const bool fill = row < 7 * F;
+                const int f = fill ? (row * 9363) >> 16 : 0, i = row - 7 * f, d = row - 7 * F, x = d - D;
+                const bool cell = d >= 0 && d < D, fre = x >= 0 && x < 3 * nfree;
+                const int qf = fre ? (x * 43) >> 7 : 0, k3 = x - 3 * qf;
+                const uint32_t flo = (uint32_t)__shfl((int)tlo, f), fhi = (uint32_t)__shfl((int)thi, f);
+                const uint32_t fw = dl[kMfxFree0 + qf];
+                const uint64_t qt = (1ull << (2 * ((fw >> 6) & 31u))) | (2ull << (2 * ((fw >> 11) & 31u)));
+                rtl[q] = fill ? flo : cell ? (d < 16 ? 1u << (2 * d) : 0u) : fre ? (uint32_t)qt : 0u;
+                rth[q] = fill ? fhi : cell ? (d >= 16 ? 1u << (2 * (d - 16)) : 0u) : fre ? (uint32_t)(qt >> 32) : 0u;
+                const int base = fill ? f * XSTAGE_F + i * XROW : cell ? X_CD + XROW * d : fre ? X_FS + XSTAGE_Q * qf + XROW * k3 : 0;
+                rbz[q] = 8u * (uint32_t)base;
+                rbc[q] = (fill || cell || fre) ? 8u * (uint32_t)(base + 12) : 8u * (uint32_t)X_Z;
+            }
+            const char *const Rb = reinterpret_cast<const char *>(Rm);
+            const int cbc = nc >> 2;                             // c: column nc & 3 of block cbc
+            const bool is_c_lane = sj == (nc & 3);
+#pragma unroll
+            for (int cb = 0; cb < XCB; ++cb) {
+                // (sjq: sj behind an opaque move, fresh per column block -- otherwise the column arithmetic of all blocks is
+                //  hoisted: lane constants that end up in scratch and come back one by one, each behind a full wait)
+                int sjq;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(sjq) : "v"(sj));
+                const int col = 4 * cb + sjq;
+                const int sd = (col * 43) >> 7;                  // column = component tt of dense slot sd
+                const uint32_t tt8 = 8u * (uint32_t)(col - 3 * sd);
+                const int sh = cb < 12 ? 2 * sd : 2 * sd - 32;   // (blocks 0 .. 11: slots 0 .. 15, the low word)
+                const uint32_t cmask = (cb == cbc && is_c_lane) ? 0xFFFFFFFFu : 0u;   // this lane's column of this block is c
+#pragma unroll
+                for (int q = 0; q < XQ; ++q) {
+                    if (q < nq && cb < ncb) {
+                        const uint32_t code = ((cb < 12 ? rtl[q] : rth[q]) >> sh) & 3u;
+                        const uint32_t a = rbz[q] + 24u * code + tt8;
+                        C[q][cb] = *reinterpret_cast<const double *>(Rb + ((rbc[q] & cmask) | (a & ~cmask)));
+                    } else {
+                        C[q][cb] = 0.0;
+                    }
+                }
+            }
+            wave_lds_sync();          // the staging area is R's from here on
+            rr = xstrip_factor(C, nc, nrows, lane, Rm);
+        }
+        wave_lds_sync();
+        // ---- R y = (Q^T c)(0:nc) by columns: lane = row ------------------------------------------------------------------
+        {
+            const int li = lane < nc ? lane : 0;
+            double ct = lane < nc ? Rm[li * XRP + nc] : 0.0;
+            const double ri = fast_rcp(Rm[li * XRP + li]);
+            const double *Rl = Rm + li * XRP;
+            int kb = (nc - 1) & ~3;
+            double c4[4], n4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c4[j] = (lane < nc && kb + j < nc) ? Rl[kb + j] : 0.0;
+            for (; kb >= 0; kb -= 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) n4[j] = (lane < nc && kb >= 4) ? Rl[kb - 4 + j] : 0.0;
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const int k = kb + j;
+                    if (k < nc) {                                             // (wave-uniform: only the first round can be short)
+                        const double yk = rl64(ct * ri, k);
+                        ct = lane < k ? fma(-yk, c4[j], ct) : ct;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c4[j] = n4[j];
+            }
+            if (lane < nc) yb[lane] = ct * ri;
+        }
+        wave_lds_sync();
+        // ---- residuals on the cell rows, weights ---------------------------------------------------------------------------
+        {
+            // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_dense: the c lane brings 1 - s, the three others their block of u . y
+            const int sl = (int)myslot;
+            double part = fma(u[2], yb[3 * sl + 2], fma(u[1], yb[3 * sl + 1], u[0] * yb[3 * sl]));
+            part = jq == 0 ? 1.0 - u[0] : part;
+            part += dpp_mov<0xB1>(part);   // quad_perm [1,0,3,2]
+            part += dpp_mov<0x4E>(part);   // quad_perm [2,3,0,1]
+            const double re = part;
+            const int ld = lane < D ? lane : 0;
+            const double ro = 1.0 - fma(dod[2], yb[3 * ld + 2], fma(dod[1], yb[3 * ld + 1], dod[0] * yb[3 * ld]));
+            const double rri = fast_rcp(rr);
+            double we = re * rri, wo = ro * rri;
+            // rank-deficient system (or NaN from a zero column): undefined in the reference, the zero row here
+            const bool ok = rr > 0.0;
+            we = (ok && __builtin_isfinite(we)) ? we : 0.0;
+            wo = (ok && __builtin_isfinite(wo)) ? wo : 0.0;
+            if (fq < F && jq == 0) wbuf[pe] = we;
+            if (lane < D) wbuf[po] = wo;
+        }
+        wave_lds_sync();
+        {
+            // gls.pyx:470-472 (only if an interior node carries the Neumann flag): neumann_ws = the last cell's weight
+            const double nwv = is_neu ? wbuf[ne - 1] : 0.0;
+            const double addv = add_neumann ? nwv : 0.0;
+            if (lane < ne) out[eb + lane] = wbuf[lane] + addv;
+            if (lane == 0) nws[p] = nwv;
+        }
+        wave_lds_sync();
+    }
+}
+
+__global__ void k_mfx_desc(GridView g, const int32_t *__restrict__ nodes, int32_t count, uint32_t *__restrict__ desc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w[kMfxDescWords];
+    if (!mfx_descriptor(g, nodes ? nodes[i] : (int32_t)i, w)) {   // (the list holds classified nodes only)
+#pragma unroll
+        for (int k = 0; k < kMfxDescWords; ++k) w[k] = 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kMfxDescWords; ++k) desc[kMfxDescWords * i + k] = w[k];
+}
+
+}  // namespace
+
+int launch_mfx_desc(const GridView &g, const int32_t *nodes, int32_t count, uint32_t *desc, hipStream_t stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_mfx_desc, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, g, nodes, count, desc);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int add_neumann, double *out,
+                   double *nws, int32_t *queue, hipStream_t stream) {
+    if (count <= 0) return 0;
+    int64_t blocks = count;
+    const int64_t cap = 4 * 256;   // persistent: one wavefront per SIMD (the whole register file of a SIMD lane belongs to one node)
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(nin_gls_mfx_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, desc, count, add_neumann, out, nws, queue);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+const char *kernel_name_gls_mfx() { return "nin_gls_mfx_kernel"; }
+
+}  // namespace nin

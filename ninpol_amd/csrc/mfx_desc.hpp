@@ -1,0 +1,117 @@
+// mfx_desc.hpp -- launch-plan descriptor of a node for kernels_gls_mfx.hip, the WIDE one-wavefront multifrontal GLS kernel
+// (internal, device code): interior nodes of unstructured meshes -- a Delaunay tetrahedrisation has 14 .. 40 cells around a
+// node, no two-colouring, and a third to a half of its nodes are beyond mfw_desc.hpp's 12 + 15 cells.
+//
+// Same decomposition as mfw_desc.hpp's general kind: F <= 16 FRONTS (cells with exactly 3 faces at the node that share no
+// face with each other: the largest of the greedy independent sets, one greedy pass per starting cell -- within 0.3 cells of
+// the exact maximum on Delaunay nodes, measured), D <= 21 DENSE cells, faces between two dense cells are FREE faces (<= 16).
+// Dense problem: (7 F + D + 3 free) x (3 D + 1) <= 160 x 64.
+//
+// 56 words per node:
+//   word 0            F | D << 8 | free faces << 16 | cells << 24
+//   word 1 + f        front f: position in the esup row (6 bits) | fsup positions of its faces 0, 1, 2 (6 bits each, << 6, 12, 18) |
+//                     bit 24 + i: the front is face i's FIRST cell (side a: row = [-B_a | +B_b], gls.pyx:340-356)
+//   word 17 + f       front f: dense slots of the cells across its faces 0, 1, 2 (5 bits each)
+//   word 33 .. 38     esup position of dense slot d, one byte each (d = 0 .. 20, slots in esup order)
+//   word 39 + q       free face q: fsup position (6 bits) | dense slot of its first cell << 6 | of its second cell << 11
+// Fronts and dense cells are numbered in esup order, free faces in fsup order.
+#pragma once
+#include <cstdint>
+
+#include "device_grid.hpp"
+
+namespace nin {
+
+constexpr int kMfxMaxFronts = 16, kMfxMaxDense = 21, kMfxMaxFree = 16, kMfxDescWords = 56;
+constexpr int kMfxMaxRows = 160, kMfxMaxCells = kMfxMaxFronts + kMfxMaxDense, kMfxMaxFaces = 63;
+constexpr int kMfxW0 = 1, kMfxW1 = 17, kMfxSlotTable = 33, kMfxFree0 = 39;
+
+#ifdef __HIPCC__
+struct MfxGraph {
+    int ne, nf;
+    uint64_t adj[kMfxMaxCells];
+    uint8_t deg[kMfxMaxCells], fa[kMfxMaxFaces], fbb[kMfxMaxFaces];   // fa / fbb: esup positions of a face's first / second cell
+};
+
+// false: a boundary face at the node, two faces between the same pair of cells, or too many cells / faces
+__device__ inline bool mfx_graph(const GridView &g, int32_t p, MfxGraph &G) {
+    const int32_t eb = g.esup_ptr[p], fb = g.fsup_ptr[p];
+    G.ne = g.esup_ptr[p + 1] - eb;
+    G.nf = g.fsup_ptr[p + 1] - fb;
+    if (g.dim != 3 || G.ne < 2 || G.ne > kMfxMaxCells || G.nf > kMfxMaxFaces || G.nf < 1) return false;
+    for (int i = 0; i < G.ne; ++i) { G.adj[i] = 0ull; G.deg[i] = 0; }
+    for (int fi = 0; fi < G.nf; ++fi) {
+        const int64_t f = g.fsup[fb + fi];
+        const int32_t a = g.face_cells[2 * f], b = g.face_cells[2 * f + 1];
+        if (b < 0) return false;
+        int ia = -1, ib = -1;
+        for (int i = 0; i < G.ne; ++i) {
+            const int32_t c = g.esup[eb + i];
+            ia = c == a ? i : ia;
+            ib = c == b ? i : ib;
+        }
+        if (ia < 0 || ib < 0 || ia == ib) return false;
+        if ((G.adj[ia] >> ib) & 1ull) return false;
+        G.adj[ia] |= 1ull << ib;
+        G.adj[ib] |= 1ull << ia;
+        ++G.deg[ia];
+        ++G.deg[ib];
+        G.fa[fi] = (uint8_t)ia;
+        G.fbb[fi] = (uint8_t)ib;
+    }
+    return true;
+}
+
+// 0: not for this kernel; 1: the words are filled
+__device__ inline int mfx_descriptor(const GridView &g, int32_t p, uint32_t w[kMfxDescWords]) {
+    MfxGraph G;
+    if (!mfx_graph(g, p, G)) return 0;
+    const int ne = G.ne, nf = G.nf;
+    if (3 * nf < 2 * ne) return 0;                         // fewer rows than unknowns next to the node value: the zero row
+    uint64_t elig = 0ull;
+    for (int i = 0; i < ne; ++i)
+        if (G.deg[i] == 3) elig |= 1ull << i;
+    uint64_t best = 0ull;
+    for (int start = 0; start < ne; ++start) {
+        uint64_t chosen = 0ull;
+        int n = 0;
+        for (int k = 0; k < ne && n < kMfxMaxFronts; ++k) {
+            const int c = start + k < ne ? start + k : start + k - ne;
+            if (((elig >> c) & 1ull) && !(G.adj[c] & chosen)) { chosen |= 1ull << c; ++n; }
+        }
+        if (n > __popcll(best)) best = chosen;
+    }
+    const int F = __popcll(best), D = ne - F, nfree = nf - 3 * F;
+    if (F < 1 || D < 1 || D > kMfxMaxDense || nfree < 0 || nfree > kMfxMaxFree) return 0;
+    if (7 * F + D + 3 * nfree > kMfxMaxRows) return 0;
+    int rank[kMfxMaxCells];                                // front number or dense slot of a cell
+    {
+        int f = 0, d = 0;
+        for (int i = 0; i < ne; ++i) rank[i] = ((best >> i) & 1ull) ? f++ : d++;
+    }
+    for (int k = 0; k < kMfxDescWords; ++k) w[k] = 0u;
+    w[0] = (uint32_t)F | ((uint32_t)D << 8) | ((uint32_t)nfree << 16) | ((uint32_t)ne << 24);
+    for (int i = 0; i < ne; ++i) {
+        if ((best >> i) & 1ull) w[kMfxW0 + rank[i]] |= (uint32_t)i;
+        else w[kMfxSlotTable + (rank[i] >> 2)] |= (uint32_t)i << (8 * (rank[i] & 3));
+    }
+    int nface[kMfxMaxFronts];
+    for (int f = 0; f < kMfxMaxFronts; ++f) nface[f] = 0;
+    int q = 0;
+    for (int fi = 0; fi < nf; ++fi) {
+        const int ia = G.fa[fi], ib = G.fbb[fi];
+        const bool a_front = ((best >> ia) & 1ull) != 0, b_front = ((best >> ib) & 1ull) != 0;
+        if (!a_front && !b_front) {
+            w[kMfxFree0 + q++] = (uint32_t)fi | ((uint32_t)rank[ia] << 6) | ((uint32_t)rank[ib] << 11);
+            continue;
+        }
+        const int fc = a_front ? ia : ib, oc = a_front ? ib : ia;
+        const int f = rank[fc], k = nface[f]++;
+        w[kMfxW0 + f] |= ((uint32_t)fi << (6 + 6 * k)) | ((a_front ? 1u : 0u) << (24 + k));
+        w[kMfxW1 + f] |= (uint32_t)rank[oc] << (5 * k);
+    }
+    return 1;
+}
+#endif
+
+}  // namespace nin

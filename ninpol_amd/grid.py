@@ -181,8 +181,8 @@ class Grid:
         """Nodes per GLS kernel of the device copy (nin_gls_plan): block kernel classes 1 / 2 / 4 / 8 wavefronts per
         node and global scratch, the cube-node kernel, the one-wavefront multifrontal kernel (two-coloured nodes large / small, general kind), the one-wavefront dense
         kernel for small nodes (at most 4 / 8 / 12 cells), the two-lanes-per-node kernel for the nodes inside a boundary
-        face of a hexahedron mesh."""
-        counts = np.zeros(13, dtype=np.int64)
+        face of a hexahedron mesh, the wide one-wavefront multifrontal kernel (interior nodes of unstructured meshes)."""
+        counts = np.zeros(14, dtype=np.int64)
         _lib.check(_lib.load().nin_gls_plan(self._h, counts.ctypes.data_as(ctypes.c_void_p)))
         return dict(zip(("block1", "block2", "block4", "block8", "scratch", "hex8", "mfw_large", "mfw_small", "mfw_general", "small4", "small8",
-                         "small12", "quad4"), counts.tolist()))
+                         "small12", "quad4", "mfx"), counts.tolist()))
