@@ -53,20 +53,45 @@ REF_FLOPS_PER_NODE_HEX = 74.8e3   # dgels 44 x 25 x 8 per interior he
 EXEC_FLOPS_PER_NODE_HEX = 16.7e3
 # ALGORITHMIC FP64 flops per node of the multifrontal formulation -- useful arithmetic only, no role masks, no redundant
 # panel work (tools/count_algorithmic_flops.py, profiles/r03/algorithmic_flops.txt) -- by node kind: (fronts, dense cells)
-ALG_FLOPS = {"cube": 15869.0, "kuhn": 250357.0, "wedge": 40075.0}
-REF_FLOPS = {"cube": 74783.0, "kuhn": 1944671.0, "wedge": 247727.0}   # dense dgels on the same nodes
+ALG_FLOPS = {"cube": 15869.0}
 
 
-def gls_flops_of_plan(plan_counts, mx_elems):
-    """Algorithmic flops one GLS launch performs on the nodes whose kind is known from the launch plan: the cube-node
-    kernel's nodes, the multifrontal kernel's Kuhn (12 + 12) nodes and its small instantiation's nodes (wedge 6 + 6 on a
-    wedge mesh, cube 4 + 4 when the cube-node kernel is off).  General-kind and block-kernel nodes (interfaces, apexes,
-    Neumann boundary nodes: 6 % of BASELINE config [3]'s computed nodes) are NOT priced -- returned as `unpriced`."""
-    small = "wedge" if mx_elems >= 12 else "cube"
-    alg = plan_counts["hex8"] * ALG_FLOPS["cube"] + plan_counts["mfw_large"] * ALG_FLOPS["kuhn"] + plan_counts["mfw_small"] * ALG_FLOPS[small]
-    ref = plan_counts["hex8"] * REF_FLOPS["cube"] + plan_counts["mfw_large"] * REF_FLOPS["kuhn"] + plan_counts["mfw_small"] * REF_FLOPS[small]
-    unpriced = sum(v for k, v in plan_counts.items() if k not in ("hex8", "mfw_large", "mfw_small"))
-    return alg, ref, unpriced
+PLAN_KERNEL_NAMES = {   # kernel of the launch plan -> its name in a rocprofv3 trace
+    "block1": "nin_gls_block_kernel<1, *>", "block2": "nin_gls_block_kernel<2, *>", "block4": "nin_gls_block_kernel<4, *>",
+    "block8": "nin_gls_block_kernel<8, *>", "scratch": "nin_gls_wave_kernel", "hex8": "nin_gls_hex8w2_kernel",
+    "mfw_large": "nin_gls_mfw_kernel<12, 12, true, false, true>", "mfw_small": "nin_gls_mfw_kernel<6, 6, true, false, false>",
+    "mfw_general": "nin_gls_mfw_kernel<12, 15, true, true, false>", "small4": "nin_gls_small_kernel<4>",
+    "small8": "nin_gls_small_kernel<8>", "small12": "nin_gls_small_kernel<12>", "quad4": "nin_gls_quad4_kernel", "mfx": "nin_gls_mfx_kernel"}
+
+
+def gls_kernel_rows(grid, launch, time_launches, reps=3):
+    """Every GLS kernel of the launch plan priced and timed on its own: nodes in its list, nodes it
+    computes (Dirichlet boundary nodes get the zero row), ALGORITHMIC flops of the formulation it runs on them
+    (nin_gls_plan_flops: per node from its own descriptor), kernel ms (NIN_GLS_ONLY=<k>: only that kernel is launched; HIP
+    events) and the fraction of the FP64 vector peak.  Returns (rows, total algorithmic flops, total reference-equivalent flops,
+    computed nodes whose kernel has no price)."""
+    plan = grid.gls_plan()
+    flops = grid.gls_plan_flops()
+    rows, alg_t, ref_t, unpriced = {}, 0.0, 0.0, 0
+    for k, name in enumerate(grid.PLAN_KERNELS):
+        if not plan[name]:
+            continue
+        alg, ref, comp = flops[name]
+        os.environ["NIN_GLS_ONLY"] = str(k)
+        try:
+            launch()
+            ms = time_launches(reps)
+        finally:
+            del os.environ["NIN_GLS_ONLY"]
+        alg_t += alg
+        ref_t += ref
+        if comp and not alg:
+            unpriced += comp
+        rows[name] = {"nodes": plan[name], "computed": comp, "ms": round(ms, 4), "algorithmic_gflop": round(alg / 1e9, 4),
+                      "kflop_per_computed_node": round(alg / comp / 1e3, 1) if comp else None,
+                      "fp64_frac": round(alg / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4) if ms > 0 else None,
+                      "ns_per_computed_node": round(ms * 1e6 / comp, 1) if comp else None, "kernel": PLAN_KERNEL_NAMES[name]}
+    return rows, alg_t, ref_t, unpriced
 
 
 def kernel_source_hash():
@@ -487,6 +512,20 @@ def main():
                 line[meth] = {"kernel_ms": round(ms, 4), "Mnodes_per_s": round(P_loc / ms / 1e3, 1),
                               "achieved_GBps": round(p2.algorithmic_bytes / (ms * 1e-3) / 1e9, 1),
                               "frac_hbm": round(p2.algorithmic_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if args.method == "gls":
+                # the kernels of the north-star mesh's own launch plan, one by one (the cube-node kernel; the Dirichlet boundary
+                # nodes' passes through the quad-node / small-node kernels)
+                def _time(nrep):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    for _ in range(nrep):
+                        plan.launch(out.data_ptr(), nws.data_ptr(), stream.cuda_stream, add_neumann=True)
+                    b.record(stream)
+                    torch.cuda.synchronize()
+                    return a.elapsed_time(b) / nrep
+                krows, alg_t, ref_t, unpriced = gls_kernel_rows(g, lambda: plan.launch(out.data_ptr(), nws.data_ptr(), stream.cuda_stream, add_neumann=True), _time, 5)
+                line["gls_kernels"] = krows
+                line["nodes_not_priced"] = int(unpriced)
             del out, nws
             torch.cuda.empty_cache()
             # host-buffer (PCIe-inclusive) path, never `value`: the first call also pins its output buffers (recycled afterwards)
@@ -513,29 +552,36 @@ def main():
                     po = Io.device_plan("u", meth)
                     oo = torch.empty(po.nnz, dtype=torch.float64, device=dev)
                     no = torch.empty(po.n_points, dtype=torch.float64, device=dev)
-                    po.launch(oo.data_ptr(), no.data_ptr(), stream.cuda_stream)
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record(stream)
-                    for _ in range(reps):
-                        po.launch(oo.data_ptr(), no.data_ptr(), stream.cuda_stream)
-                    b.record(stream)
-                    torch.cuda.synchronize()
-                    ms = a.elapsed_time(b) / reps
+                    launch = lambda: po.launch(oo.data_ptr(), no.data_ptr(), stream.cuda_stream)
+
+                    def time_launches(n):
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record(stream)
+                        for _ in range(n):
+                            launch()
+                        b.record(stream)
+                        torch.cuda.synchronize()
+                        return a.elapsed_time(b) / n
+                    launch()
+                    ms = time_launches(reps)
                     gb = po.algorithmic_bytes / (ms * 1e-3) / 1e9
                     row = {"kernel_ms": round(ms, 3), "Mnodes_per_s": round(Io.grid.n_points / ms / 1e3, 2),
                            "achieved_GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBS, 4)}
-                    if meth == "gls":   # the roof that binds GLS: FP64 vector, algorithmic flops of the multifrontal formulation
-                        alg, ref, unpriced = gls_flops_of_plan(Io.grid.gls_plan(), Io.grid.MX_ELEMENTS_PER_POINT)
+                    if meth == "gls":   # the roof that binds GLS: FP64 vector, algorithmic flops of the formulation each kernel runs
+                        krows, alg, ref, unpriced = gls_kernel_rows(Io.grid, launch, time_launches, reps)
                         row.update({"fp64_algorithmic_tflops": round(alg / (ms * 1e-3) / 1e12, 3),
                                     "fp64_frac": round(alg / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
                                     "fp64_ref_equiv_frac": round(ref / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
-                                    "nodes_not_priced": int(unpriced)})
+                                    "nodes_not_priced": int(unpriced), "gls_kernels": krows})
                     return row
                 rows = {}
                 for name, make, meths in (
                         ("[1],[2] hex 100^3", lambda: M.hex_mesh(100, jitter=args.jitter), ("idw", "gls")),
                         ("[3] hex|pyramid|tet mix 200x120x120", lambda: M.mixed_mesh(200, 120, 120, jitter=0.1), ("gls",)),
-                        ("kuhn tets 40^3", lambda: M.tet_mesh(40, jitter=0.1), ("gls",))):
+                        ("kuhn tets 40^3", lambda: M.tet_mesh(40, jitter=0.1), ("gls",)),
+                        # round 4: UNSTRUCTURED tetrahedra, the mesh class of the reference's tetra numbers (performance.yaml:184-246):
+                        # the Delaunay tetrahedrisation of a jittered body-centred cloud, ~2 M cells, 14 .. 40 cells around a node
+                        ("unstructured tets (Delaunay of a jittered 54^3 body-centred cloud)", lambda: M.delaunay_tet_mesh(54, seed=0), ("gls",))):
                     mo = make()
                     M.attach_fields(mo, "u", perm="ALH")
                     Io = ninpol_amd.Interpolator(device=local_rank, grid_build="device")
@@ -544,6 +590,10 @@ def main():
                     for meth in meths:
                         row[meth] = timed(Io, meth)
                     row["gls_nodes_per_kernel"] = {k: v for k, v in Io.grid.gls_plan().items() if v}
+                    n_int = int((~np.asarray(Io.grid.boundary_points).astype(bool)).sum())
+                    pl = Io.grid.gls_plan()
+                    row["interior_nodes_off_the_block_kernel"] = round(
+                        (pl["hex8"] + pl["mfw_large"] + pl["mfw_small"] + pl["mfw_general"] + pl["mfx"]) / max(n_int, 1), 4)
                     rows[name] = row
                     del Io, mo
                     torch.cuda.empty_cache()

@@ -200,6 +200,14 @@ const char *nin_kernel_name(int method);
  * gls.pyx:138-197, for every node.) */
 int nin_gls_plan(const nin_grid *g, int64_t counts[14]);
 
+/* Measurement: the FP64 flops one GLS launch performs, kernel by kernel of the launch plan (numbered as in
+ * nin_gls_plan): alg[k] = ALGORITHMIC flops of the formulation kernel k runs on its nodes (fronts + dense rest for the
+ * multifrontal kernels, from each node's own descriptor; one dense Householder QR with the last-row identity for the small-node /
+ * one-wavefront block / global-scratch kernels), ref[k] = the reference's dense dgels on the same nodes (gls.pyx:420-474),
+ * computed[k] = the nodes that are computed at all (Dirichlet boundary nodes and nodes outside the parity set get the zero row).
+ * Needs nin_fields_set (the Neumann flags decide which boundary nodes are computed). */
+int nin_gls_plan_flops(nin_grid *g, double alg[14], double ref[14], int64_t computed[14]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ EXPORTS = (
     "nin_grid_array_info", "nin_grid_array_copy", "nin_device_count", "nin_grid_to_device", "nin_grid_device",
     "nin_fields_set", "nin_weights_device", "nin_weights_host", "nin_csr_compact_host", "nin_interpolate_csr_host", "nin_apply_host",
     "nin_apply_device", "nin_apply_fields_host", "nin_pack_connectivity", "nin_pack_table_row", "nin_diff_mag",
-    "nin_algorithmic_bytes", "nin_kernel_name", "nin_gls_plan", "nin_host_alloc", "nin_host_free", "nin_hash64",
+    "nin_algorithmic_bytes", "nin_kernel_name", "nin_gls_plan", "nin_gls_plan_flops", "nin_host_alloc", "nin_host_free", "nin_hash64",
     "nin_grid_release_scratch",
 )
 
@@ -71,6 +71,7 @@ def load():
     L.nin_kernel_name.argtypes = [i32]
     L.nin_kernel_name.restype = cp
     L.nin_gls_plan.argtypes = [vp, vp]
+    L.nin_gls_plan_flops.argtypes = [vp, vp, vp, vp]
     L.nin_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     L.nin_host_free.argtypes = [vp]
     L.nin_hash64.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]

@@ -75,7 +75,16 @@ def build(force=False, verbose_resources=False):
         objs.append(obj)
     _run(["g++", "-shared", "-o", LIB] + objs +
          ["-L", os.path.join(ROCM, "lib"), "-lamdhip64", "-lgomp", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+    build_tools()
     return LIB
+
+
+def build_tools():
+    """Stand-alone device test programs (tests/test_gpu_parity.py runs them on the GPU box): tools/_bin/test_xstrip."""
+    tools = os.path.join(os.path.dirname(HERE), "tools")
+    os.makedirs(os.path.join(tools, "_bin"), exist_ok=True)
+    _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-I", CSRC, os.path.join(tools, "test_xstrip.hip"), "-o",
+          os.path.join(tools, "_bin", "test_xstrip")])
 
 
 if __name__ == "__main__":

@@ -76,6 +76,9 @@ void dev_free_all(DeviceGrid &d) {
     if (d.ev_scan) (void)hipEventDestroy(static_cast<hipEvent_t>(d.ev_scan));
     if (d.copy_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(d.copy_stream));
     if (d.copy_stream2) (void)hipStreamDestroy(static_cast<hipStream_t>(d.copy_stream2));
+    if (d.ev_fork) (void)hipEventDestroy(static_cast<hipEvent_t>(d.ev_fork));
+    if (d.ev_join) (void)hipEventDestroy(static_cast<hipEvent_t>(d.ev_join));
+    if (d.side_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(d.side_stream));
     for (void *p : d.allocs) (void)hipFree(p);
     d.allocs.clear();
     d = DeviceGrid{};
@@ -650,14 +653,59 @@ static int launch_class(DeviceGrid &d, int c, const int32_t *nodes, int32_t coun
                             d.gls_scratch_stride, d.gls_scratch_slots, stream);
 }
 
-// every GLS kernel of the launch plan but the cube-node kernel, all their nodes (the work counters are zeroed by the caller)
+// The global-scratch class first, on the side stream: entries [b, b + n) of its list.  Ordered behind everything enqueued on
+// `stream` so far (the zeroed work counters, the caller's buffers) and joined by gls_side_end.  NIN_GLS_NO_SIDE_STREAM=1: off.
+static int gls_side_begin(DeviceGrid &d, int add_neumann, double *out, double *nws, hipStream_t stream, int32_t b, int32_t n) {
+    d.side_pending = false;
+    if (n <= 0 || getenv("NIN_GLS_NO_SIDE_STREAM") != nullptr) return 0;
+    if (!d.side_stream) {
+        hipStream_t s = nullptr;
+        hipEvent_t a = nullptr, e = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+            return -3;
+        d.side_stream = s; d.ev_fork = a; d.ev_join = e;
+    }
+    hipStream_t side = static_cast<hipStream_t>(d.side_stream);
+    if (hipEventRecord(static_cast<hipEvent_t>(d.ev_fork), stream) != hipSuccess || hipStreamWaitEvent(side, static_cast<hipEvent_t>(d.ev_fork), 0) != hipSuccess)
+        return -3;
+    const auto &k = d.gls[kGlsClasses - 1];
+    int rc = launch_gls_class(d.v, k.nodes ? k.nodes + b : nullptr, n, 0, k.rows_per_lane, add_neumann, out, nws, d.gls_scratch, d.gls_scratch_stride,
+                              d.gls_scratch_slots, side);
+    if (!rc && hipEventRecord(static_cast<hipEvent_t>(d.ev_join), side) != hipSuccess) rc = -3;
+    d.side_pending = rc == 0;
+    return rc;
+}
+static int gls_side_end(DeviceGrid &d, hipStream_t stream) {
+    if (!d.side_pending) return 0;
+    d.side_pending = false;
+    return hipStreamWaitEvent(stream, static_cast<hipEvent_t>(d.ev_join), 0) == hipSuccess ? 0 : -3;
+}
+
+// NIN_GLS_ONLY=<k>: launch only kernel k of the plan, numbered as nin_gls_plan counts them (measurement: bench.py times the
+// kernels of a plan one by one; read at every launch)
+static int gls_only() {
+    const char *e = getenv("NIN_GLS_ONLY");
+    return e && *e ? atoi(e) : -1;
+}
+
+// every GLS kernel of the launch plan but the cube-node kernel, all their nodes (the work counters are zeroed by the caller; the
+// global-scratch class is left out if gls_side_begin took it)
 static int launch_gls_but_cube(DeviceGrid &d, int add_neumann, double *out, double *nws, hipStream_t stream) {
     int rc = 0;
-    for (int i = 0; i < 3 && !rc; ++i) rc = launch_mfw(d, d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, i, add_neumann, out, nws, stream);
-    for (int i = 0; i < 3 && !rc; ++i) rc = launch_gls_small(d.v, d.small[i].nodes, d.small[i].count, i, add_neumann, out, nws, stream);
-    if (!rc) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, out, nws, stream);
-    if (!rc) rc = launch_gls_mfx(d.v, d.mfx.nodes, d.mfx_desc, d.mfx.count, add_neumann, out, nws, d.gls_queue + 8, stream);   // (work counter: int 8)
-    for (int c = 0; c < kGlsClasses && !rc; ++c) rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, out, nws, stream);
+    const int only = gls_only();
+    auto on = [&](int k) { return only < 0 || only == k; };
+    for (int i = 0; i < 3 && !rc; ++i)
+        if (on(6 + i)) rc = launch_mfw(d, d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, i, add_neumann, out, nws, stream);
+    for (int i = 0; i < 3 && !rc; ++i)
+        if (on(9 + i)) rc = launch_gls_small(d.v, d.small[i].nodes, d.small[i].count, i, add_neumann, out, nws, stream);
+    if (!rc && on(12)) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, out, nws, stream);
+    if (!rc && on(13)) rc = launch_gls_mfx(d.v, d.mfx.nodes, d.mfx_desc, d.mfx.count, add_neumann, out, nws, d.gls_queue + 8, stream);   // (work counter: int 8)
+    for (int c = 0; c < kGlsClasses && !rc; ++c) {
+        if ((c == kGlsClasses - 1 && d.side_pending) || !on(c)) continue;
+        rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, out, nws, stream);
+    }
+    if (!rc) rc = gls_side_end(d, stream);
     return rc;
 }
 
@@ -683,7 +731,10 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
         else {
             HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
-            rc = launch_hex8(d, d.hex8.nodes, d.hex8_desc, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
+            const int only = gls_only();
+            if (only < 0) rc = gls_side_begin(d, add_neumann, dev_csr_data, dev_neumann_ws, stream, 0, d.gls[kGlsClasses - 1].count);
+            if (!rc && (only < 0 || only == 5))
+                rc = launch_hex8(d, d.hex8.nodes, d.hex8_desc, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             if (!rc) rc = launch_gls_but_cube(d, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         }
         if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -892,10 +943,11 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
         return launch_rows_range(d.v, method == NIN_METHOD_LS ? 1 : 0, P, d.chunk_node[k], d.chunk_node[k + 1],
                                  (int32_t)g->h.mx_elems_per_point, out, nws, stream);
     HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
-    int rc = 0;
+    int rc = gls_side_begin(d, 1, out, nws, stream, d.chunk_off[kGlsClasses - 1][k],
+                            d.chunk_off[kGlsClasses - 1][k + 1] - d.chunk_off[kGlsClasses - 1][k]);
     {
         const int32_t b = d.chunk_off[kGlsClasses][k], n = d.chunk_off[kGlsClasses][k + 1] - b;
-        if (n > 0) rc = launch_gls_hex8mf(d.v, d.hex8.nodes + b, d.hex8_desc + 4 * (size_t)b, n, 1, out, nws, d.gls_queue, stream);
+        if (!rc && n > 0) rc = launch_gls_hex8mf(d.v, d.hex8.nodes + b, d.hex8_desc + 4 * (size_t)b, n, 1, out, nws, d.gls_queue, stream);
     }
     for (int i = 0; i < 3 && !rc; ++i) {
         const int32_t b = d.chunk_off[kGlsClasses + 1 + i][k], n = d.chunk_off[kGlsClasses + 1 + i][k + 1] - b;
@@ -920,10 +972,11 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
         const auto &kc = d.gls[c];
         if (c < kGlsClasses - 1)
             rc = launch_gls_block(d.v, kc.nodes + b, n, kc.waves, kc.col_slots, kc.lds_bytes, 1, out, nws, d.gls_queue + 1 + c, stream);
-        else
+        else if (!d.side_pending)
             rc = launch_gls_class(d.v, kc.nodes + b, n, 0, kc.rows_per_lane, 1, out, nws, d.gls_scratch, d.gls_scratch_stride,
                                   d.gls_scratch_slots, stream);
     }
+    if (!rc) rc = gls_side_end(d, stream);
     return rc ? fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError())) : NIN_OK;
 }
 
@@ -1079,8 +1132,9 @@ int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t
         if (!d.have_perm) return fail(NIN_ESTATE, "GLS needs permeability and diff_mag");
         if (d.gls_too_large) return fail(NIN_ERANGE, "a node's GLS system has more than 1024 rows: beyond the fallback kernel");
         HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));
-        int rc = launch_gls_hex8mf_apply(d.v, d.hex8.nodes, d.hex8_desc, d.hex8.count, 1, dev_u_cells, n_fields, dev_node_values,
-                                         dev_neumann_ws, d.gls_queue, stream);
+        int rc = gls_side_begin(d, 1, d.apply_weights, dev_neumann_ws, stream, 0, d.gls[kGlsClasses - 1].count);
+        if (!rc) rc = launch_gls_hex8mf_apply(d.v, d.hex8.nodes, d.hex8_desc, d.hex8.count, 1, dev_u_cells, n_fields, dev_node_values,
+                                              dev_neumann_ws, d.gls_queue, stream);
         if (!rc) rc = launch_gls_but_cube(d, 1, d.apply_weights, dev_neumann_ws, stream);
         if (!rc) rc = launch_apply_list(d.v, d.apply_weights, dev_u_cells, n_fields, dev_node_values, d.noncube_nodes, d.noncube_count, stream);
         if (rc) return fail(rc, "launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1154,6 +1208,122 @@ int nin_host_free(void *ptr) {
     if (!ptr) return NIN_OK;
     const hipError_t e = hipHostFree(ptr);
     if (e != hipSuccess) return fail(NIN_EHIP, "hipHostFree: %s", hipGetErrorString(e));
+    return NIN_OK;
+}
+
+// ---- algorithmic flops of a launch plan, kernel by kernel (tools/count_algorithmic_flops.py holds the same formulas) ----
+namespace {
+// n_pivot Householder steps on an m-row block with n_cols columns in all (pivot columns included): 2 m for the norm, 8 for the
+// scalar chain, 4 m per trailing column (dot + update)
+double hh_flops(int64_t m, int64_t n_pivot, int64_t n_cols) {
+    double f = 0;
+    for (int64_t k = 0; k < n_pivot; ++k) {
+        const double rows = (double)(m - k);
+        f += 2 * rows + 8 + 4 * rows * (double)(n_cols - k - 1);
+    }
+    return f;
+}
+// fronts of 3-face cells + a dense rest (kernels_gls_hex8mf / mfw / mfx): F fronts, D dense cells, `faces` internal faces of which
+// `free_faces` join two dense cells
+double multifrontal_flops(int64_t F, int64_t D, int64_t faces, int64_t free_faces) {
+    const double face = 52.0 * faces;
+    const double p1 = F * (hh_flops(10, 3, 3 + 9 + 1) + 9 + 54 + 6);
+    const int64_t m2 = 7 * F + D + 3 * free_faces, n2 = 3 * D;
+    const double p2 = hh_flops(m2, n2, n2 + 1);
+    const double tail = (double)n2 * n2 + F * (2 * 9 + 2) + D * (2 * 3 + 1) + 2 * (m2 - n2) + (F + D) + 1;
+    return face + p1 + p2 + tail;
+}
+// the dense m x (n + 1) system with the last-row identity (one Householder QR of the first n columns, no right-hand sides):
+// the small-node, block (one wavefront) and global-scratch kernels; n_if internal faces, n_nb Neumann rows
+double dense_flops(int64_t ne, int64_t n_if, int64_t n_nb) {
+    const int64_t m = ne + 3 * n_if + n_nb, n = 3 * ne;
+    return 52.0 * n_if + 15.0 * n_nb + hh_flops(m, n, n + 1) + (double)n * n + 7.0 * ne + 2.0 * (m - n) + ne + 1;
+}
+// dgels on the reference's dense m x n system with nrhs right-hand sides
+double dgels_flops(double m, double n, double nrhs) { return 2 * m * n * n - 2 * n * n * n / 3 + nrhs * (4 * m * n - 2 * n * n) + nrhs * n * n; }
+}  // namespace
+
+int nin_gls_plan_flops(nin_grid *g, double alg[14], double ref[14], int64_t computed[14]) {
+    if (!g || !alg || !ref || !computed) return fail(NIN_EINVAL, "NULL argument");
+    DeviceGrid &d = g->d;
+    HostGrid &h = g->h;
+    if (d.device < 0 || d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
+    if (!d.fields_set || !d.flag_staging) return fail(NIN_ESTATE, "nin_fields_set has not been called (the Neumann flags decide which boundary nodes are computed)");
+    if (h.ensure(A_ESUP_PTR | A_ESUP | A_FSUP_PTR | A_FSUP | A_ESUF)) return fail(NIN_EHIP, "mirroring the connectivity failed");
+    HIP_TRY(hipSetDevice(d.device));
+    for (int k = 0; k < 14; ++k) { alg[k] = ref[k] = 0.0; computed[k] = 0; }
+    const int64_t P = h.n_points;
+    // (F, D, free faces) of the nodes of the multifrontal kernels: from their descriptors
+    std::vector<uint32_t> fdq((size_t)P, 0u);
+    auto read_desc = [&](const int32_t *nodes, const uint32_t *desc, int32_t count, int words, int word) -> int {
+        if (count <= 0) return 0;
+        std::vector<int32_t> hn((size_t)count);
+        std::vector<uint32_t> hd((size_t)count * words);
+        if (hipMemcpy(hn.data(), nodes, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+        if (hipMemcpy(hd.data(), desc, hd.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+        for (int32_t i = 0; i < count; ++i) fdq[hn[i]] = hd[(size_t)i * words + word] & 0xFFFFFFu;
+        return 0;
+    };
+    for (int i = 0; i < 3; ++i)
+        if (read_desc(d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, kMfwDescWords, 24)) return fail(NIN_EHIP, "reading the descriptors back failed");
+    if (read_desc(d.mfx.nodes, d.mfx_desc, d.mfx.count, kMfxDescWords, 0)) return fail(NIN_EHIP, "reading the descriptors back failed");
+    for (int64_t p = 0; p < P; ++p) {
+        const int c = g->node_class[p];
+        const int k = c == 255 ? 5 : (c >= 252 && c <= 254) ? 6 + (254 - c) : (c >= 249 && c <= 251) ? 9 + (c - 249) : c == 248 ? 12 : c == 247 ? 13 : c;
+        const int fl = d.flag_staging[p];
+        if ((fl & 1) && !(fl & 2)) continue;                   // a Dirichlet boundary node: the zero row, nothing computed (gls.pyx:165-166)
+        const int64_t eb = h.esup_ptr[p], ne = h.esup_ptr[p + 1] - eb, fb = h.fsup_ptr[p], nf = h.fsup_ptr[p + 1] - fb;
+        int64_t n_if = 0;
+        for (int64_t q = fb; q < fb + nf; ++q) {
+            const int64_t f = h.fsup[q];
+            n_if += h.esuf_ptr[f + 1] - h.esuf_ptr[f] > 1;
+        }
+        const int64_t n_bf = nf - n_if, n_nb = (fl & 2) ? n_bf : 0;
+        const int64_t m = ne + 3 * n_if + n_nb;
+        if (n_if == 0 || m < 3 * ne) continue;                 // outside the parity set: the zero row
+        ++computed[k];
+        ref[k] += dgels_flops((double)(ne + 3 * nf + n_nb), (double)(3 * ne + 1), (double)(ne + (n_nb ? 1 : 0)));
+        if (k == 5) alg[k] += multifrontal_flops(4, 4, 12, 0);
+        else if ((k >= 6 && k <= 8) || k == 13) {
+            const uint32_t w = fdq[p];
+            alg[k] += multifrontal_flops(w & 255u, (w >> 8) & 255u, n_if, (w >> 16) & 255u);
+        } else if (k == 12) {
+            // two fronts of 8 rows (cell row, two internal faces, the Neumann row) x (3 | 6 | c), then 14 x 6 over the pair
+            alg[k] += 52.0 * 4 + 15.0 * 4 + 2 * (hh_flops(8, 3, 3 + 6 + 1) + 9 + 36 + 6) + hh_flops(14, 6, 7) + 36 + 2 * 20 + 2 * 7 + 2 * 8 + 5;
+        } else if (k >= 1 && k <= 3) {
+            // the block kernel on more than one wavefront: fronts = the greedy independent set (esup order) of the cells with 1 .. 4
+            // internal faces at the node that own no Neumann row; a front of a cell with f faces is (1 + 3 f) x (3 + 3 f + 1)
+            const int n_c = (int)std::min<int64_t>(ne, 64);
+            uint64_t adj[64] = {0};
+            int nfi[64] = {0};
+            uint64_t blocked = 0;
+            for (int64_t q = fb; q < fb + nf; ++q) {
+                const int64_t f = h.fsup[q], e0 = h.esuf_ptr[f];
+                const bool internal = h.esuf_ptr[f + 1] - e0 > 1;
+                int ia = -1, ib = -1;
+                for (int i = 0; i < n_c; ++i) {
+                    if (h.esup[eb + i] == h.esuf[e0]) ia = i;
+                    if (internal && h.esup[eb + i] == h.esuf[e0 + 1]) ib = i;
+                }
+                if (internal && ia >= 0 && ib >= 0) { adj[ia] |= 1ull << ib; adj[ib] |= 1ull << ia; ++nfi[ia]; ++nfi[ib]; }
+                else if (!internal && ia >= 0 && n_nb) blocked |= 1ull << ia;
+            }
+            uint64_t chosen = 0;
+            double p1 = 0;
+            int64_t rows_gone = 0, Fb = 0;
+            for (int i = 0; i < n_c; ++i)
+                if (nfi[i] >= 1 && nfi[i] <= 4 && !((blocked >> i) & 1ull) && !(adj[i] & chosen)) {
+                    chosen |= 1ull << i;
+                    p1 += hh_flops(1 + 3 * nfi[i], 3, 3 + 3 * nfi[i] + 1);
+                    rows_gone += 3;
+                    ++Fb;
+                }
+            const int64_t m2 = m - rows_gone, n2 = 3 * (ne - Fb);
+            alg[k] += 52.0 * n_if + 15.0 * n_nb + p1 + hh_flops(m2, n2, n2 + 1) + (double)(3 * ne) * (3 * ne) + 7.0 * ne + 2.0 * (m - 3 * ne) + ne + 1;
+        } else {
+            alg[k] += dense_flops(ne, n_if, n_nb);             // small-node kernel, block kernel on one wavefront, global scratch
+        }
+    }
     return NIN_OK;
 }
 

@@ -105,6 +105,11 @@ struct DeviceGrid {
     uint8_t *flag_staging = nullptr;   // page-locked [n_points]: nin_fields_set packs the node flags here and uploads from it
     void *copy_stream = nullptr, *copy_stream2 = nullptr;   // hipStream_t of the device-to-host copies that run under the kernels
     void *ev_weights = nullptr, *ev_scan = nullptr;   // hipEvent_t: weights written / row pointers scanned
+    // The long pole of a GLS launch plan: the few nodes of the global-scratch class (more cells than any in-register / in-LDS kernel
+    // holds: ~0.03 % of a Delaunay mesh) take ~2 ms EACH on a wavefront of their own.  They start first, on a stream of their own,
+    // and run under the other kernels (abi.hip: gls_side_begin / gls_side_end).
+    void *side_stream = nullptr, *ev_fork = nullptr, *ev_join = nullptr;
+    bool side_pending = false;
     // interpolate()'s pipeline (abi.hip, interpolate_chunked): the node range is cut into kE2eChunks pieces at multiples of 64 nodes;
     // every GLS list is ascending, so a piece is a sub-range of each: chunk_off[list][k] .. chunk_off[list][k + 1]
     // (lists 0 .. kGlsClasses - 1: the block kernel's classes, then the cube-node kernel, the three mfw kinds, the three small kinds, the quad nodes, the wide multifrontal kernel)

@@ -60,6 +60,9 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
         if (lane == 0) v = atomicAdd(queue, 1);
         return __builtin_amdgcn_readfirstlane(v);
     };
+#ifdef NIN_MFX_STAMPS
+    int n_done = 0;
+#endif
     for (int32_t idx = ticket(); idx < count; idx = ticket()) {
         const int32_t p = __builtin_amdgcn_readfirstlane(nodes ? nodes[idx] : idx);
         const uint32_t *dw = desc + (size_t)kMfxDescWords * idx;
@@ -240,7 +243,11 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
                 const uint32_t cmask = (cb == cbc && is_c_lane) ? 0xFFFFFFFFu : 0u;   // this lane's column of this block is c
 #pragma unroll
                 for (int q = 0; q < XQ; ++q) {
+#if defined(NIN_MFX_SKIP) && (NIN_MFX_SKIP & 4)
+                    if (q < 0) {
+#else
                     if (q < nq && cb < ncb) {
+#endif
                         const uint32_t code = ((cb < 12 ? rtl[q] : rth[q]) >> sh) & 3u;
                         const uint32_t a = rbz[q] + 24u * code + tt8;
                         C[q][cb] = *reinterpret_cast<const double *>(Rb + ((rbc[q] & cmask) | (a & ~cmask)));
@@ -250,10 +257,30 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
                 }
             }
             wave_lds_sync();          // the staging area is R's from here on
-            rr = xstrip_factor(C, nc, nrows, lane, Rm);
+#if defined(NIN_MFX_SKIP) && (NIN_MFX_SKIP & 1)    // (timing builds, tools/build_variant.sh: a phase left out; the results are wrong)
+            rr = C[0][0] + C[XQ - 1][XCB - 1] + 1.0;
+#else
+            XStamps ST;
+#ifdef NIN_MFX_STAMPS
+            ST.on = blockIdx.x == 0 && n_done == 3;
+            ST.last = __builtin_amdgcn_s_memtime();
+            for (int j = 0; j < 6; ++j) ST.acc[j] = 0;
+            const unsigned long long t_begin = ST.last;
+#endif
+            rr = xstrip_factor(C, nc, nrows, lane, Rm, ST);
+#ifdef NIN_MFX_STAMPS
+            if (ST.on && lane == 0) {
+                for (int j = 0; j < 5; ++j) nws[nodes[j]] = (double)ST.acc[j];
+                nws[nodes[5]] = (double)(__builtin_amdgcn_s_memtime() - t_begin);
+                nws[nodes[6]] = (double)nrows;
+                nws[nodes[7]] = (double)nc;
+            }
+#endif
+#endif
         }
         wave_lds_sync();
         // ---- R y = (Q^T c)(0:nc) by columns: lane = row ------------------------------------------------------------------
+#if !(defined(NIN_MFX_SKIP) && (NIN_MFX_SKIP & 2))
         {
             const int li = lane < nc ? lane : 0;
             double ct = lane < nc ? Rm[li * XRP + nc] : 0.0;
@@ -279,6 +306,7 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
             }
             if (lane < nc) yb[lane] = ct * ri;
         }
+#endif
         wave_lds_sync();
         // ---- residuals on the cell rows, weights ---------------------------------------------------------------------------
         {
@@ -306,7 +334,11 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
             const double nwv = is_neu ? wbuf[ne - 1] : 0.0;
             const double addv = add_neumann ? nwv : 0.0;
             if (lane < ne) out[eb + lane] = wbuf[lane] + addv;
+#ifndef NIN_MFX_STAMPS
             if (lane == 0) nws[p] = nwv;
+#else
+            ++n_done;
+#endif
         }
         wave_lds_sync();
     }

@@ -59,7 +59,14 @@ __device__ __forceinline__ void xpanel_step(double (&C)[XQ][XCB], double &PT, do
 
 // The dense factorisation of an nrows x (nc + 1) problem held in the tiles (c at column nc; rows and columns beyond: zeros).  On
 // exit R's rows 0 .. nc - 1 (columns up to nc = Q^T c) are in LDS at Rm[row * XRP + col]; returns r . r = |(Q^T c)(nc:)|^2.
-__device__ __forceinline__ double xstrip_factor(double (&C)[XQ][XCB], int nc, int nrows, int lane, double *Rm) {
+#ifdef NIN_MFX_STAMPS   // diagnostic build (tools/stamps_mfx.py): s_memtime between the pieces of a panel, summed over the panels
+struct XStamps { unsigned long long last, acc[6]; bool on; };
+#define NIN_XSUB(ST, J) do { if ((ST).on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); (ST).acc[J] += t_ - (ST).last; (ST).last = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+struct XStamps { };
+#define NIN_XSUB(ST, J) do { } while (0)
+#endif
+__device__ __forceinline__ double xstrip_factor(double (&C)[XQ][XCB], int nc, int nrows, int lane, double *Rm, XStamps &ST) {
     const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3, rowbase = 4 * sb + si;
     const double eye = si == sj ? 1.0 : 0.0;                     // the 4 x 4 identity in every quad
     const int n_panels = (nc + 3) >> 2, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
@@ -90,6 +97,7 @@ __device__ __forceinline__ double xstrip_factor(double (&C)[XQ][XCB], int nc, in
         const bool r_rows = sb == bp && si < steps;
         const int col0 = 4 * p + sj;
         double *dst = Rm + (4 * p + si) * XRP + col0;
+        NIN_XSUB(ST, 0);   // panel factored
         if (r_rows && sj >= si && col0 <= nc) dst[0] = PT;
         // (a panel with fewer than four pivots is the last one: c sits in its block, nothing lies to the right of it; the rows of
         //  the pivot tile below its pivots count in r . r: the tile goes back to its place)
@@ -102,6 +110,7 @@ __device__ __forceinline__ double xstrip_factor(double (&C)[XQ][XCB], int nc, in
             double W[XCB];
 #pragma unroll
             for (int cb = 1; cb < XCB; ++cb) W[cb] = 0.0;
+            NIN_XSUB(ST, 1);   // V, T, first rows of R
             // W[cb] = V^T C[.][cb]: four independent accumulation chains per group of column blocks
 #pragma unroll
             for (int q = 0; q < XQ; ++q) {
@@ -115,6 +124,7 @@ __device__ __forceinline__ double xstrip_factor(double (&C)[XQ][XCB], int nc, in
                     }
                 }
             }
+            NIN_XSUB(ST, 2);   // W = V^T C
 #pragma unroll
             for (int g4 = 0; g4 < (XCB + 2) / 4; ++g4) {
                 if (4 * g4 + 1 <= nt) {
@@ -122,6 +132,7 @@ __device__ __forceinline__ double xstrip_factor(double (&C)[XQ][XCB], int nc, in
                     for (int cb = 4 * g4 + 1; cb < 4 * g4 + 5 && cb < XCB; ++cb) W[cb] = mfma4(Ts, sum_quads(W[cb]), 0.0);   // -(T^T W), the same in every quad
                 }
             }
+            NIN_XSUB(ST, 3);   // T^T W
             // C -= V W', written ONE BLOCK DOWN: the next panel (or c) lands in block 0 without a move.  Blocks beyond nt are
             // never read again (their contents are whatever the group's last sweep left there)
 #pragma unroll
@@ -145,6 +156,7 @@ __device__ __forceinline__ double xstrip_factor(double (&C)[XQ][XCB], int nc, in
                     }
                 }
             }
+            NIN_XSUB(ST, 4);   // update, rows of R stored
         }
     }
     // c sits in block 0, column nc & 3; r . r over the rows that never were pivot rows

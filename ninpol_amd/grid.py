@@ -177,6 +177,17 @@ class Grid:
         at 10 M cells); the next call allocates them again."""
         _lib.check(_lib.load().nin_grid_release_scratch(self._h))
 
+    PLAN_KERNELS = ("block1", "block2", "block4", "block8", "scratch", "hex8", "mfw_large", "mfw_small", "mfw_general", "small4", "small8",
+                    "small12", "quad4", "mfx")
+
+    def gls_plan_flops(self):
+        """Per kernel of the GLS launch plan (nin_gls_plan_flops): {kernel: (algorithmic flops, reference-equivalent dgels flops,
+        nodes computed)} for one launch over all nodes; needs the fields on the device (a DevicePlan or an interpolate() first)."""
+        alg, ref, comp = np.zeros(14), np.zeros(14), np.zeros(14, dtype=np.int64)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(_lib.load().nin_gls_plan_flops(self._h, p(alg), p(ref), p(comp)))
+        return {k: (float(alg[i]), float(ref[i]), int(comp[i])) for i, k in enumerate(self.PLAN_KERNELS)}
+
     def gls_plan(self):
         """Nodes per GLS kernel of the device copy (nin_gls_plan): block kernel classes 1 / 2 / 4 / 8 wavefronts per
         node and global scratch, the cube-node kernel, the one-wavefront multifrontal kernel (two-coloured nodes large / small, general kind), the one-wavefront dense

@@ -33,6 +33,7 @@ def _meshes():
     yield "wedge7", M.wedge_mesh(7, 5, 4, jitter=0.05, seed=2)
     yield "mixed", M.mixed_mesh(10, 6, 6, jitter=0.1, seed=3)
     yield "quad_tri_2d", M.quad_tri_mesh_2d(11, 8, jitter=0.1, seed=4)
+    yield "delaunay9", M.delaunay_tet_mesh(9, seed=7)
 
 
 @pytest.mark.parametrize("name,mesh", list(_meshes()), ids=[m[0] for m in _meshes()])

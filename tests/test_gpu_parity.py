@@ -43,6 +43,8 @@ def _meshes():
     yield "tet7_jitter", M.tet_mesh(7, jitter=0.1, seed=1), "ALH", (1, 0.0)
     yield "wedge8", M.wedge_mesh(8, 6, 5, jitter=0.05, seed=2), "ALH", (2, 1.0)
     yield "mixed1266", M.mixed_mesh(12, 6, 6, jitter=0.1, seed=3), "ALH", (2, 1.0)
+    yield "delaunay10", M.delaunay_tet_mesh(10, seed=4), "ALH", (2, 0.0)
+    yield "delaunay8_random_cloud_fan", M.delaunay_tet_mesh(8, seed=9, lattice="random"), "FAN", (0, 1.0)
 
 
 @pytest.mark.parametrize("name,mesh,perm,plane", list(_meshes()), ids=[m[0] for m in _meshes()])
@@ -382,6 +384,50 @@ def test_gpu_multifrontal_general_kind(oracle_lib, monkeypatch):
     # (the pyramid apexes -- 7 cells, 43 rows -- fit the small-node kernel and go there; with it off they are general-kind nodes)
     assert got[False]["mfw_general"] == int(np.sum(~bp & np.isin(ne, (16, 26))))
     assert got[False]["small8"] >= int(np.sum(~bp & (ne == 7)))
+
+
+@pytest.mark.parametrize("lattice,perm", [("bcc", "ALH"), ("bcc", "FAN"), ("random", "LIN")])
+def test_gpu_wide_multifrontal_kernel_on_unstructured_tetrahedra(oracle_lib, monkeypatch, lattice, perm):
+    """A Delaunay tetrahedrisation: 14 .. 40+ cells around an interior node, no two-colouring, a third of the nodes beyond the
+    general kind's 12 + 15 cells (the mesh class of the reference's tetra numbers).  Three routes
+    against the oracle: the default plan (general kind + the wide kernel), NIN_GLS_MFX_ALL (every general node through the wide
+    kernel), NIN_GLS_NO_MFX (round 3's route: the block kernel) -- and the plan itself: at least 95 % of the interior nodes
+    stay off the block / scratch kernels by default."""
+    mesh = M.delaunay_tet_mesh(11, seed=21, lattice=lattice)
+    M.attach_fields(mesh, "u", perm=perm, neumann_plane=(1, 0.0), seed=2)
+    o = oracle_lib.OracleInterpolator("port", threads=8)
+    o.load_mesh(mesh)
+    wo, no = o.prepare("gls", "u")
+    plans = {}
+    for route in ("default", "NIN_GLS_MFX_ALL", "NIN_GLS_NO_MFX"):
+        if route != "default":
+            monkeypatch.setenv(route, "1")
+        I = _interp()
+        I.load_mesh(mesh_obj=mesh)
+        w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+        assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL, route
+        assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL, route
+        plans[route] = I.grid.gls_plan()
+        if route != "default":
+            monkeypatch.delenv(route)
+    n_interior = int(np.sum(~np.asarray(I.grid.boundary_points).astype(bool)))
+    one_wave = lambda p: p["mfw_large"] + p["mfw_small"] + p["mfw_general"] + p["mfx"] + p["hex8"]
+    assert plans["default"]["mfx"] > 0 and plans["NIN_GLS_NO_MFX"]["mfx"] == 0
+    assert plans["NIN_GLS_MFX_ALL"]["mfw_general"] == 0 and plans["NIN_GLS_MFX_ALL"]["mfx"] > plans["default"]["mfx"]
+    # (the interior nodes the block kernel keeps: more than 16 + 21 cells -- the random cloud has a few per cent of them)
+    assert one_wave(plans["default"]) >= (0.95 if lattice == "bcc" else 0.85) * n_interior, (plans["default"], n_interior)
+    assert one_wave(plans["NIN_GLS_NO_MFX"]) < one_wave(plans["default"])
+
+
+def test_gpu_wide_kernel_dense_phase_alone():
+    """mfx_strips.hpp's xstrip_factor -- the blocked Householder QR in register tiles behind the wide kernel -- on random
+    problems of every size class against a host QR (tools/test_xstrip.hip, compiled by __graft_entry__.build())."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_bin", "test_xstrip")
+    assert os.path.exists(exe), "python -c 'import __graft_entry__ as g; g.build()' builds it"
+    r = subprocess.run([exe, "--no-timing"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
 
 
 @pytest.mark.parametrize("sectors,layers", [(15, 3), (30, 3), (50, 2), (80, 2)])

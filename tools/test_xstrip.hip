@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "mfx_strips.hpp"
@@ -25,10 +26,50 @@ __global__ __launch_bounds__(64) void k_factor(const double *A, int lda, int nc,
             C[q][cb] = (row < nrows && col <= nc) ? A[row * lda + col] : 0.0;
         }
     __syncthreads();
-    const double rr = xstrip_factor(C, nc, nrows, lane, Rm);
+    XStamps ST;
+    const double rr = xstrip_factor(C, nc, nrows, lane, Rm, ST);
     __syncthreads();
     for (int i = lane; i < 64 * XRP; i += 64) Rout[i] = Rm[i];
     if (lane == 0) *rr_out = rr;
+}
+
+__global__ __launch_bounds__(64) void k_time(const double *A, int lda, int nc, int nrows, double *Rout, int reps) {
+    __shared__ double Rm[64 * XRP];
+    const int lane = threadIdx.x, si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
+    double acc = 0.0;
+    for (int it = 0; it < reps; ++it) {
+        double C[XQ][XCB];
+#pragma unroll
+        for (int q = 0; q < XQ; ++q)
+#pragma unroll
+            for (int cb = 0; cb < XCB; ++cb) {
+                const int row = 16 * q + 4 * sb + si, col = 4 * cb + sj;
+                C[q][cb] = (row < nrows && col <= nc) ? A[row * lda + col] + acc : 0.0;
+            }
+        XStamps ST;
+        acc += 1e-300 * xstrip_factor(C, nc, nrows, lane, Rm, ST);
+    }
+    Rout[(size_t)blockIdx.x * 64 + lane] = acc + Rm[lane];
+}
+
+// the same through mfw_strips.hpp's unrolled strip_factor (one body per half-generation, no branches): the A/B baseline
+__global__ __launch_bounds__(64) void k_time_unrolled(const double *A, int lda, int nc, int nrows, double *Rout, int reps) {
+    __shared__ double Rm[64 * XRP];
+    const int lane = threadIdx.x, si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
+    double acc = 0.0;
+    for (int it = 0; it < reps; ++it) {
+        double C[XQ][XCB];
+#pragma unroll
+        for (int q = 0; q < XQ; ++q)
+#pragma unroll
+            for (int cb = 0; cb < XCB; ++cb) {
+                const int row = 16 * q + 4 * sb + si, col = 4 * cb + sj;
+                C[q][cb] = (row < nrows && col <= nc) ? A[row * lda + col] + acc : 0.0;
+            }
+        nin::mfwstrips::SubStamps ST;
+        acc += 1e-300 * nin::mfwstrips::strip_factor<XQ, XCB>(C, nc, lane, Rm, XRP, ST);
+    }
+    Rout[(size_t)blockIdx.x * 64 + lane] = acc + Rm[lane];
 }
 
 // host: Householder QR of the nrows x (nc + 1) matrix on its first nc columns; returns R (nc x (nc + 1)) and |(Q^T c)(nc:)|^2
@@ -55,7 +96,8 @@ static void host_qr(std::vector<double> a, int lda, int nrows, int nc, std::vect
     for (int r = nc; r < nrows; ++r) rr += a[r * lda + nc] * a[r * lda + nc];
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool timing = !(argc > 1 && std::string(argv[1]) == "--no-timing");
     const int lda = 64;
     std::mt19937_64 gen(1);
     std::normal_distribution<double> nd;
@@ -91,6 +133,39 @@ int main() {
         bad += !ok;
         printf("%3d x %2d: max |R - R_host| / max|R| = %.2e at (%d, %d)   rr %.6e vs %.6e (%.1e)  %s\n", nrows, nc, erel, wi, wj, rrg, rr, err_rr,
                ok ? "ok" : "FAIL");
+    }
+    // timing: the same 118 x 48 problem on 1 / 256 / 1024 / 2048 wavefronts (blocks of one wave), 20 factorisations each
+    if (timing) {
+        const int nrows = 118, nc = 48;
+        std::vector<double> A((size_t)160 * lda, 0.0);
+        for (int r = 0; r < nrows; ++r)
+            for (int c = 0; c <= nc; ++c) A[r * lda + c] = nd(gen);
+        hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+        double *dRb;
+        hipMalloc(&dRb, (size_t)4096 * 64 * XRP * 8);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int blocks : {1, 1024}) {
+            hipLaunchKernelGGL(k_time_unrolled, dim3(blocks), dim3(64), 0, 0, dA, lda, nc, nrows, dRb, 2);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_time_unrolled, dim3(blocks), dim3(64), 0, 0, dA, lda, nc, nrows, dRb, 20);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("timing %d x %d, UNROLLED strip_factor<10,16> (sweeps all 160 x 64): %5d waves: %.1f us each per wave\n", nrows, nc, blocks, ms * 1e3 / 20);
+        }
+        for (int blocks : {1, 256, 1024, 2048, 4096}) {
+            hipLaunchKernelGGL(k_time, dim3(blocks), dim3(64), 0, 0, dA, lda, nc, nrows, dRb, 2);
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_time, dim3(blocks), dim3(64), 0, 0, dA, lda, nc, nrows, dRb, 20);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("timing %d x %d: %5d waves x 20 factorisations: %.3f ms = %.1f us each per wave = %.1f ns per factorisation chip-wide\n", nrows, nc, blocks, ms,
+                   ms * 1e3 / 20, ms * 1e6 / 20 / blocks);
+        }
     }
     printf(bad ? "FAILED %d cases\n" : "all ok\n", bad);
     return bad ? 1 : 0;
