@@ -467,7 +467,10 @@ int nin_grid_to_device(nin_grid *g, int device) {
                           (getenv("NIN_GLS_NO_SMALL") == nullptr ? 8 : 0) |         // (bit 3: the one-wavefront dense kernel for small nodes)
                           (getenv("NIN_GLS_NO_QUAD4") == nullptr ? 16 : 0) |        // (bit 4: the two-lanes-per-node kernel for quad nodes)
                           (getenv("NIN_GLS_NO_MFX") == nullptr ? 32 : 0) |          // (bit 5: the wide multifrontal kernel: unstructured meshes)
-                          (getenv("NIN_GLS_MFX_ALL") != nullptr ? 64 : 0);          // (bit 6: ... takes the general kind's nodes too)
+                          (getenv("NIN_GLS_MFW_GENERAL") == nullptr ? 64 : 0);      // (bit 6: ... takes the general kind's nodes too -- the default
+                                                                                    //  since its dense phase runs straight-line per size class: 37 against
+                                                                                    //  38 ns a node on a Delaunay mesh, equal on the mixed mesh; NIN_GLS_MFW_GENERAL=1
+                                                                                    //  gives the nodes that fit back to kernels_gls_mfw.hip's general kind)
     const bool force_global = getenv("NIN_GLS_FORCE_GLOBAL") != nullptr;   // testing switch: systems in global scratch
     int64_t need_max[kGlsClasses] = {0}, rows_max[kGlsClasses] = {0}, cols_max[kGlsClasses] = {0};
     {

@@ -566,6 +566,9 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
         int32_t d[4];   // the hex8 kernel needs the cells to form the cube graph (hex8_desc.hpp)
         if (hex8_descriptor(g, (int32_t)p, d)) { node_class[p] = 255; return; }
     }
+    // (general-kind nodes that fit the small-node kernel -- pyramid apexes: 7 cells, 43 rows -- are cheaper there: 26.64 -> 26.54 ms
+    //  on BASELINE config [3])
+    const bool small_fits = (use_group & 8) && !force_global && g.dim == 3 && ne <= 12 && nf <= 48 && ne + 3 * nf <= 64;
     if ((use_group & 2) && nbf == 0 && ne <= kMfwMaxCells) {
         uint32_t w[kMfwDescWords];   // fronts of 3-face cells that share no face + dense cells (mfw_desc.hpp)
         const int kind = mfw_descriptor(g, (int32_t)p, w);
@@ -574,14 +577,11 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
             node_class[p] = (F <= kMfwSmallFronts && D <= kMfwSmallDense) ? 253 : 254;
             return;
         }
-        // (general-kind nodes that fit the small-node kernel -- pyramid apexes: 7 cells, 43 rows -- are cheaper there: 26.64 -> 26.54 ms
-        //  on BASELINE config [3])
-        const bool small_fits = (use_group & 8) && !force_global && g.dim == 3 && ne <= 12 && nf <= 48 && ne + 3 * nf <= 64;
-        // (bit 6: the wide kernel takes the general kind's nodes too -- A/B switch)
+        // (bit 6: the wide kernel takes the general kind's nodes too -- the default; NIN_GLS_MFW_GENERAL=1 clears it)
         if (kind == 2 && (use_group & 4) && !small_fits && !(use_group & 64)) { node_class[p] = 252; return; }
     }
-    // interior nodes of unstructured meshes: more cells than the kinds above hold (kernels_gls_mfx.hip, mfx_desc.hpp)
-    if ((use_group & 32) && !force_global && nbf == 0 && ne <= kMfxMaxCells && ne > 12) {
+    // interior nodes of unstructured meshes: more cells than the kinds above hold, no two-colouring (kernels_gls_mfx.hip, mfx_desc.hpp)
+    if ((use_group & 32) && !force_global && nbf == 0 && ne <= kMfxMaxCells && !small_fits) {
         uint32_t w[kMfxDescWords];
         if (mfx_descriptor(g, (int32_t)p, w)) { node_class[p] = 247; return; }
     }

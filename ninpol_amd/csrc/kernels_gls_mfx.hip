@@ -44,6 +44,78 @@ constexpr int X_Y = XNP * XRP + 1, X_W = X_Y + 64, X_Z = X_W + 40, X_DESC = X_Z 
 static_assert(X_FS + kMfxMaxFree * XSTAGE_Q <= XNP * XRP, "the staging area lies under R");
 static_assert(16 * XQ >= kMfxMaxRows && 4 * XCB >= XNP + 1 && (X_DESC & 1) == 0, "tiles");
 
+// The dense phase of one node: gather the rows from the staging area into TQ x TCB tiles (16 rows x 4 columns each), factor.
+// SINGLE: the one-body form (xstrip_factor: wave-uniform branches, work proportional to the node -- and ~50 cycles a taken
+// branch); otherwise mfw_strips.hpp's unrolled strip_factor<TQ, TCB>, straight-line, which sweeps the whole class size.
+template <int TQ, int TCB, bool SINGLE>
+__device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, int nc, int nrows, int F, int D, int nfree, int lane) {
+    static_assert(!SINGLE || (TQ == XQ && TCB == XCB), "the single-body form has one size");
+    const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
+    const int nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
+    double C[TQ][TCB];
+    // code(sd) = 1 + the index of dense slot sd among the row's cells (0: not one of them), two bits per slot; a front's
+    // table is made once (lane f) and shuffled
+    uint32_t tlo = 0u, thi = 0u;
+    {
+        const uint32_t wbl = dl[kMfxW1 + (lane < kMfxMaxFronts ? lane : 0)];
+        const uint64_t t = (1ull << (2 * (wbl & 31u))) | (2ull << (2 * ((wbl >> 5) & 31u))) | (3ull << (2 * ((wbl >> 10) & 31u)));
+        tlo = lane < F ? (uint32_t)t : 0u;
+        thi = lane < F ? (uint32_t)(t >> 32) : 0u;
+    }
+    // per tile row q, this lane's row: rtl / rth = the 2-bit codes of its cells' slots (slots 0 .. 15 / 16 .. 20), rbz = the
+    // byte address of the row in the staging area (the lanes of rows that do not exist read front 0's zeros), rbc = of its c
+    uint32_t rtl[TQ], rth[TQ], rbz[TQ], rbc[TQ];
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+        const int row = 16 * q + 4 * sb + si;
+        const bool fill = row < 7 * F;
+        const int f = fill ? (row * 9363) >> 16 : 0, i = row - 7 * f, d = row - 7 * F, x = d - D;
+        const bool cell = d >= 0 && d < D, fre = x >= 0 && x < 3 * nfree;
+        const int qf = fre ? (x * 43) >> 7 : 0, k3 = x - 3 * qf;
+        const uint32_t flo = (uint32_t)__shfl((int)tlo, f), fhi = (uint32_t)__shfl((int)thi, f);
+        const uint32_t fw = dl[kMfxFree0 + qf];
+        const uint64_t qt = (1ull << (2 * ((fw >> 6) & 31u))) | (2ull << (2 * ((fw >> 11) & 31u)));
+        rtl[q] = fill ? flo : cell ? (d < 16 ? 1u << (2 * d) : 0u) : fre ? (uint32_t)qt : 0u;
+        rth[q] = fill ? fhi : cell ? (d >= 16 ? 1u << (2 * (d - 16)) : 0u) : fre ? (uint32_t)(qt >> 32) : 0u;
+        const int base = fill ? f * XSTAGE_F + i * XROW : cell ? X_CD + XROW * d : fre ? X_FS + XSTAGE_Q * qf + XROW * k3 : 0;
+        rbz[q] = 8u * (uint32_t)base;
+        rbc[q] = (fill || cell || fre) ? 8u * (uint32_t)(base + 12) : 8u * (uint32_t)X_Z;
+    }
+    const char *const Rb = reinterpret_cast<const char *>(Rm);
+    const int cbc = nc >> 2;                             // c: column nc & 3 of block cbc
+    const bool is_c_lane = sj == (nc & 3);
+#pragma unroll
+    for (int cb = 0; cb < TCB; ++cb) {
+        // (sjq: sj behind an opaque move, fresh per column block -- otherwise the column arithmetic of all blocks is
+        //  hoisted: lane constants that end up in scratch and come back one by one, each behind a full wait)
+        int sjq;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(sjq) : "v"(sj));
+        const int col = 4 * cb + sjq;
+        const int sd = (col * 43) >> 7;                  // column = component tt of dense slot sd
+        const uint32_t tt8 = 8u * (uint32_t)(col - 3 * sd);
+        const int sh = cb < 12 ? 2 * sd : 2 * sd - 32;   // (blocks 0 .. 11: slots 0 .. 15, the low word)
+        const uint32_t cmask = (cb == cbc && is_c_lane) ? 0xFFFFFFFFu : 0u;   // this lane's column of this block is c
+#pragma unroll
+        for (int q = 0; q < TQ; ++q) {
+            if (!SINGLE || (q < nq && cb < ncb)) {     // (straight-line in the class instantiations: rows / columns beyond the node read zeros)
+                const uint32_t code = ((cb < 12 ? rtl[q] : rth[q]) >> sh) & 3u;
+                const uint32_t a = rbz[q] + 24u * code + tt8;
+                C[q][cb] = *reinterpret_cast<const double *>(Rb + ((rbc[q] & cmask) | (a & ~cmask)));
+            } else {
+                C[q][cb] = 0.0;
+            }
+        }
+    }
+    wave_lds_sync();          // the staging area is R's from here on
+    if constexpr (SINGLE) {
+        XStamps ST;
+        return xstrip_factor(C, nc, nrows, lane, Rm, ST);
+    } else {
+        SubStamps ST;
+        return strip_factor<TQ, TCB>(C, nc, lane, Rm, XRP, ST);
+    }
+}
+
 __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32_t *__restrict__ nodes, const uint32_t *__restrict__ desc,
                                                         int32_t count, int add_neumann, double *__restrict__ out,
                                                         double *__restrict__ nws, int32_t *__restrict__ queue) {
@@ -60,9 +132,6 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
         if (lane == 0) v = atomicAdd(queue, 1);
         return __builtin_amdgcn_readfirstlane(v);
     };
-#ifdef NIN_MFX_STAMPS
-    int n_done = 0;
-#endif
     for (int32_t idx = ticket(); idx < count; idx = ticket()) {
         const int32_t p = __builtin_amdgcn_readfirstlane(nodes ? nodes[idx] : idx);
         const uint32_t *dw = desc + (size_t)kMfxDescWords * idx;
@@ -194,93 +263,22 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
         wave_lds_sync();
 
         const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
-        const int nrows = 7 * F + D + 3 * nfree, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
+        const int nrows = 7 * F + D + 3 * nfree;
+        // ---- the dense problem in 16 x 4 tiles: rows = the fronts' 7 fill rows each, the D cell rows, 3 rows per free face.  One
+        //      straight-line instantiation per size class (a lone wavefront pays ~50 cycles for every taken branch: the single-body
+        //      form with wave-uniform branches, xstrip_factor, is 1.9 x slower on the same problem -- tools/test_xstrip.hip)
         double rr;
-        {
-            // ---- the dense problem in 16 x 4 tiles: rows = the fronts' 7 fill rows each, the D cell rows, 3 rows per free face --
-            double C[XQ][XCB];
-            // code(sd) = 1 + the index of dense slot sd among the row's cells (0: not one of them), two bits per slot; a front's
-            // table is made once (lane f) and shuffled
-            uint32_t tlo = 0u, thi = 0u;
-            {
-                const uint32_t wbl = dl[kMfxW1 + (lane < kMfxMaxFronts ? lane : 0)];
-                const uint64_t t = (1ull << (2 * (wbl & 31u))) | (2ull << (2 * ((wbl >> 5) & 31u))) | (3ull << (2 * ((wbl >> 10) & 31u)));
-                tlo = lane < F ? (uint32_t)t : 0u;
-                thi = lane < F ? (uint32_t)(t >> 32) : 0u;
-            }
-            // per tile row q, this lane's row: rtl / rth = the 2-bit codes of its cells' slots (slots 0 .. 15 / 16 .. 20), rbz = the
-            // byte address of the row in the staging area (the lanes of rows that do not exist read front 0's zeros), rbc = of its c
-            uint32_t rtl[XQ], rth[XQ], rbz[XQ], rbc[XQ];
-#pragma unroll
-            for (int q = 0; q < XQ; ++q) {
-                const int row = 16 * q + 4 * sb + si;
-                const bool fill = row < 7 * F;
-                const int f = fill ? (row * 9363) >> 16 : 0, i = row - 7 * f, d = row - 7 * F, x = d - D;
-                const bool cell = d >= 0 && d < D, fre = x >= 0 && x < 3 * nfree;
-                const int qf = fre ? (x * 43) >> 7 : 0, k3 = x - 3 * qf;
-                const uint32_t flo = (uint32_t)__shfl((int)tlo, f), fhi = (uint32_t)__shfl((int)thi, f);
-                const uint32_t fw = dl[kMfxFree0 + qf];
-                const uint64_t qt = (1ull << (2 * ((fw >> 6) & 31u))) | (2ull << (2 * ((fw >> 11) & 31u)));
-                rtl[q] = fill ? flo : cell ? (d < 16 ? 1u << (2 * d) : 0u) : fre ? (uint32_t)qt : 0u;
-                rth[q] = fill ? fhi : cell ? (d >= 16 ? 1u << (2 * (d - 16)) : 0u) : fre ? (uint32_t)(qt >> 32) : 0u;
-                const int base = fill ? f * XSTAGE_F + i * XROW : cell ? X_CD + XROW * d : fre ? X_FS + XSTAGE_Q * qf + XROW * k3 : 0;
-                rbz[q] = 8u * (uint32_t)base;
-                rbc[q] = (fill || cell || fre) ? 8u * (uint32_t)(base + 12) : 8u * (uint32_t)X_Z;
-            }
-            const char *const Rb = reinterpret_cast<const char *>(Rm);
-            const int cbc = nc >> 2;                             // c: column nc & 3 of block cbc
-            const bool is_c_lane = sj == (nc & 3);
-#pragma unroll
-            for (int cb = 0; cb < XCB; ++cb) {
-                // (sjq: sj behind an opaque move, fresh per column block -- otherwise the column arithmetic of all blocks is
-                //  hoisted: lane constants that end up in scratch and come back one by one, each behind a full wait)
-                int sjq;
-                asm volatile("v_mov_b32 %0, %1" : "=v"(sjq) : "v"(sj));
-                const int col = 4 * cb + sjq;
-                const int sd = (col * 43) >> 7;                  // column = component tt of dense slot sd
-                const uint32_t tt8 = 8u * (uint32_t)(col - 3 * sd);
-                const int sh = cb < 12 ? 2 * sd : 2 * sd - 32;   // (blocks 0 .. 11: slots 0 .. 15, the low word)
-                const uint32_t cmask = (cb == cbc && is_c_lane) ? 0xFFFFFFFFu : 0u;   // this lane's column of this block is c
-#pragma unroll
-                for (int q = 0; q < XQ; ++q) {
-#if defined(NIN_MFX_SKIP) && (NIN_MFX_SKIP & 4)
-                    if (q < 0) {
+#if defined(NIN_MFX_SINGLE_BODY)
+        rr = dense_phase<XQ, XCB, true>(Rm, dl, nc, nrows, F, D, nfree, lane);
 #else
-                    if (q < nq && cb < ncb) {
+        if (nrows <= 96 && nc < 40) rr = dense_phase<6, 10, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
+        else if (nrows <= 112 && nc < 44) rr = dense_phase<7, 11, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
+        else if (nrows <= 128 && nc < 52) rr = dense_phase<8, 13, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
+        else if (nrows <= 144 && nc < 60) rr = dense_phase<9, 15, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
+        else rr = dense_phase<XQ, XCB, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
 #endif
-                        const uint32_t code = ((cb < 12 ? rtl[q] : rth[q]) >> sh) & 3u;
-                        const uint32_t a = rbz[q] + 24u * code + tt8;
-                        C[q][cb] = *reinterpret_cast<const double *>(Rb + ((rbc[q] & cmask) | (a & ~cmask)));
-                    } else {
-                        C[q][cb] = 0.0;
-                    }
-                }
-            }
-            wave_lds_sync();          // the staging area is R's from here on
-#if defined(NIN_MFX_SKIP) && (NIN_MFX_SKIP & 1)    // (timing builds, tools/build_variant.sh: a phase left out; the results are wrong)
-            rr = C[0][0] + C[XQ - 1][XCB - 1] + 1.0;
-#else
-            XStamps ST;
-#ifdef NIN_MFX_STAMPS
-            ST.on = blockIdx.x == 0 && n_done == 3;
-            ST.last = __builtin_amdgcn_s_memtime();
-            for (int j = 0; j < 6; ++j) ST.acc[j] = 0;
-            const unsigned long long t_begin = ST.last;
-#endif
-            rr = xstrip_factor(C, nc, nrows, lane, Rm, ST);
-#ifdef NIN_MFX_STAMPS
-            if (ST.on && lane == 0) {
-                for (int j = 0; j < 5; ++j) nws[nodes[j]] = (double)ST.acc[j];
-                nws[nodes[5]] = (double)(__builtin_amdgcn_s_memtime() - t_begin);
-                nws[nodes[6]] = (double)nrows;
-                nws[nodes[7]] = (double)nc;
-            }
-#endif
-#endif
-        }
         wave_lds_sync();
         // ---- R y = (Q^T c)(0:nc) by columns: lane = row ------------------------------------------------------------------
-#if !(defined(NIN_MFX_SKIP) && (NIN_MFX_SKIP & 2))
         {
             const int li = lane < nc ? lane : 0;
             double ct = lane < nc ? Rm[li * XRP + nc] : 0.0;
@@ -306,7 +304,6 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
             }
             if (lane < nc) yb[lane] = ct * ri;
         }
-#endif
         wave_lds_sync();
         // ---- residuals on the cell rows, weights ---------------------------------------------------------------------------
         {
@@ -334,11 +331,7 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
             const double nwv = is_neu ? wbuf[ne - 1] : 0.0;
             const double addv = add_neumann ? nwv : 0.0;
             if (lane < ne) out[eb + lane] = wbuf[lane] + addv;
-#ifndef NIN_MFX_STAMPS
             if (lane == 0) nws[p] = nwv;
-#else
-            ++n_done;
-#endif
         }
         wave_lds_sync();
     }

@@ -367,6 +367,8 @@ def test_gpu_multifrontal_general_kind(oracle_lib, monkeypatch):
     o.load_mesh(mesh)
     wo, no = o.prepare("gls", "u")
     got = {}
+    monkeypatch.setenv("NIN_GLS_MFW_GENERAL", "1")       # (round 4: by default the wide kernel takes these nodes, next test)
+    monkeypatch.setenv("NIN_GLS_NO_MFX", "1")
     for off in (False, True):
         if off:
             monkeypatch.setenv("NIN_GLS_NO_MFW_GENERAL", "1")
@@ -374,7 +376,7 @@ def test_gpu_multifrontal_general_kind(oracle_lib, monkeypatch):
         I.load_mesh(mesh_obj=mesh)
         I.grid.to_device(0)
         plan = I.grid.gls_plan()
-        assert (plan["mfw_general"] == 0) == off and plan["mfw_large"] > 0
+        assert (plan["mfw_general"] == 0) == off and plan["mfw_large"] > 0 and plan["mfx"] == 0
         w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
         assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL, off
         assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL, off
@@ -386,12 +388,32 @@ def test_gpu_multifrontal_general_kind(oracle_lib, monkeypatch):
     assert got[False]["small8"] >= int(np.sum(~bp & (ne == 7)))
 
 
+def test_gpu_wide_kernel_takes_the_general_kind_by_default(oracle_lib):
+    """The hex | pyramid and pyramid | tet interface nodes of a mixed mesh (16 and 26 cells, odd cycles) go to the wide
+    multifrontal kernel by default (round 4); the pyramid apexes (7 cells) stay with the small-node kernel."""
+    mesh = M.mixed_mesh(10, 5, 5, jitter=0.1, seed=11)
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=5)
+    o = oracle_lib.OracleInterpolator("port", threads=4)
+    o.load_mesh(mesh)
+    wo, no = o.prepare("gls", "u")
+    I = _interp()
+    I.load_mesh(mesh_obj=mesh)
+    w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+    assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL and util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
+    plan = I.grid.gls_plan()
+    ne = np.diff(np.asarray(I.grid.esup_ptr))
+    bp = np.asarray(I.grid.boundary_points).astype(bool)
+    assert plan["mfx"] == int(np.sum(~bp & np.isin(ne, (16, 26)))) and plan["mfw_general"] == 0
+    assert plan["small8"] >= int(np.sum(~bp & (ne == 7)))
+
+
 @pytest.mark.parametrize("lattice,perm", [("bcc", "ALH"), ("bcc", "FAN"), ("random", "LIN")])
 def test_gpu_wide_multifrontal_kernel_on_unstructured_tetrahedra(oracle_lib, monkeypatch, lattice, perm):
     """A Delaunay tetrahedrisation: 14 .. 40+ cells around an interior node, no two-colouring, a third of the nodes beyond the
     general kind's 12 + 15 cells (the mesh class of the reference's tetra numbers).  Three routes
-    against the oracle: the default plan (general kind + the wide kernel), NIN_GLS_MFX_ALL (every general node through the wide
-    kernel), NIN_GLS_NO_MFX (round 3's route: the block kernel) -- and the plan itself: at least 95 % of the interior nodes
+    against the oracle: the default plan (every node that is not two-coloured through the wide kernel), NIN_GLS_MFW_GENERAL (the
+    nodes that fit 12 + 15 cells through kernels_gls_mfw.hip's general kind, the rest through the wide kernel), NIN_GLS_NO_MFX
+    (round 3's route: general kind + block kernel) -- and the plan itself: at least 95 % of the interior nodes
     stay off the block / scratch kernels by default."""
     mesh = M.delaunay_tet_mesh(11, seed=21, lattice=lattice)
     M.attach_fields(mesh, "u", perm=perm, neumann_plane=(1, 0.0), seed=2)
@@ -399,7 +421,7 @@ def test_gpu_wide_multifrontal_kernel_on_unstructured_tetrahedra(oracle_lib, mon
     o.load_mesh(mesh)
     wo, no = o.prepare("gls", "u")
     plans = {}
-    for route in ("default", "NIN_GLS_MFX_ALL", "NIN_GLS_NO_MFX"):
+    for route in ("default", "NIN_GLS_MFW_GENERAL", "NIN_GLS_NO_MFX"):
         if route != "default":
             monkeypatch.setenv(route, "1")
         I = _interp()
@@ -412,8 +434,8 @@ def test_gpu_wide_multifrontal_kernel_on_unstructured_tetrahedra(oracle_lib, mon
             monkeypatch.delenv(route)
     n_interior = int(np.sum(~np.asarray(I.grid.boundary_points).astype(bool)))
     one_wave = lambda p: p["mfw_large"] + p["mfw_small"] + p["mfw_general"] + p["mfx"] + p["hex8"]
-    assert plans["default"]["mfx"] > 0 and plans["NIN_GLS_NO_MFX"]["mfx"] == 0
-    assert plans["NIN_GLS_MFX_ALL"]["mfw_general"] == 0 and plans["NIN_GLS_MFX_ALL"]["mfx"] > plans["default"]["mfx"]
+    assert plans["default"]["mfx"] > 0 and plans["default"]["mfw_general"] == 0 and plans["NIN_GLS_NO_MFX"]["mfx"] == 0
+    assert plans["NIN_GLS_MFW_GENERAL"]["mfw_general"] > 0 and 0 < plans["NIN_GLS_MFW_GENERAL"]["mfx"] < plans["default"]["mfx"]
     # (the interior nodes the block kernel keeps: more than 16 + 21 cells -- the random cloud has a few per cent of them)
     assert one_wave(plans["default"]) >= (0.95 if lattice == "bcc" else 0.85) * n_interior, (plans["default"], n_interior)
     assert one_wave(plans["NIN_GLS_NO_MFX"]) < one_wave(plans["default"])

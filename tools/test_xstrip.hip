@@ -53,21 +53,22 @@ __global__ __launch_bounds__(64) void k_time(const double *A, int lda, int nc, i
 }
 
 // the same through mfw_strips.hpp's unrolled strip_factor (one body per half-generation, no branches): the A/B baseline
+template <int TQ, int TCB>
 __global__ __launch_bounds__(64) void k_time_unrolled(const double *A, int lda, int nc, int nrows, double *Rout, int reps) {
     __shared__ double Rm[64 * XRP];
     const int lane = threadIdx.x, si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
     double acc = 0.0;
     for (int it = 0; it < reps; ++it) {
-        double C[XQ][XCB];
+        double C[TQ][TCB];
 #pragma unroll
-        for (int q = 0; q < XQ; ++q)
+        for (int q = 0; q < TQ; ++q)
 #pragma unroll
-            for (int cb = 0; cb < XCB; ++cb) {
+            for (int cb = 0; cb < TCB; ++cb) {
                 const int row = 16 * q + 4 * sb + si, col = 4 * cb + sj;
                 C[q][cb] = (row < nrows && col <= nc) ? A[row * lda + col] + acc : 0.0;
             }
         nin::mfwstrips::SubStamps ST;
-        acc += 1e-300 * nin::mfwstrips::strip_factor<XQ, XCB>(C, nc, lane, Rm, XRP, ST);
+        acc += 1e-300 * nin::mfwstrips::strip_factor<TQ, TCB>(C, nc, lane, Rm, XRP, ST);
     }
     Rout[(size_t)blockIdx.x * 64 + lane] = acc + Rm[lane];
 }
@@ -145,15 +146,19 @@ int main(int argc, char **argv) {
         hipMalloc(&dRb, (size_t)4096 * 64 * XRP * 8);
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int blocks : {1, 1024}) {
-            hipLaunchKernelGGL(k_time_unrolled, dim3(blocks), dim3(64), 0, 0, dA, lda, nc, nrows, dRb, 2);
+        auto time_unrolled = [&](auto kern, const char *what, int blocks) {
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, dA, lda, nc, nrows, dRb, 2);
             hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(k_time_unrolled, dim3(blocks), dim3(64), 0, 0, dA, lda, nc, nrows, dRb, 20);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, dA, lda, nc, nrows, dRb, 20);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
-            printf("timing %d x %d, UNROLLED strip_factor<10,16> (sweeps all 160 x 64): %5d waves: %.1f us each per wave\n", nrows, nc, blocks, ms * 1e3 / 20);
+            printf("timing %d x %d, UNROLLED strip_factor%s: %5d waves: %.1f us each per wave\n", nrows, nc, what, blocks, ms * 1e3 / 20);
+        };
+        for (int blocks : {1, 1024}) {
+            time_unrolled(k_time_unrolled<10, 16>, "<10,16> (sweeps all 160 x 64)", blocks);
+            time_unrolled(k_time_unrolled<8, 13>, "<8,13> (128 x 52: the exact class)", blocks);
         }
         for (int blocks : {1, 256, 1024, 2048, 4096}) {
             hipLaunchKernelGGL(k_time, dim3(blocks), dim3(64), 0, 0, dA, lda, nc, nrows, dRb, 2);
