@@ -294,6 +294,7 @@ def test_gpu_block_kernel_where_mfw_would_run(oracle_lib, monkeypatch, kind):
     for off in (False, True):
         if off:
             monkeypatch.setenv("NIN_GLS_NO_MFW", "1")
+            monkeypatch.setenv("NIN_GLS_NO_MFX", "1")
             monkeypatch.setenv("NIN_GLS_NO_SMALL", "1")
         I = _interp()
         I.load_mesh(mesh_obj=mesh)
@@ -302,11 +303,11 @@ def test_gpu_block_kernel_where_mfw_would_run(oracle_lib, monkeypatch, kind):
         w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
         assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL, off
         assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL, off
-    assert plans[True]["mfw_large"] == 0 and plans[True]["mfw_small"] == 0 and plans[True]["mfw_general"] == 0
+    assert plans[True]["mfw_large"] == 0 and plans[True]["mfw_small"] == 0 and plans[True]["mfw_general"] == 0 and plans[True]["mfx"] == 0
     taken = plans[False]["mfw_large"] + plans[False]["mfw_small"]
     assert taken == {"tet": 4 ** 3, "wedge": 4 ** 3}.get(kind, taken) and taken > 0
-    # the general kind (free faces, up to 15 dense cells): the hex | pyramid | tet interfaces and pyramid apexes of the mix
-    assert (plans[False]["mfw_general"] > 0) == (kind == "mixed")
+    # the nodes that are not two-coloured (free faces): the hex | pyramid | tet interfaces of the mix -- the wide kernel's by default
+    assert (plans[False]["mfx"] > 0) == (kind == "mixed") and plans[False]["mfw_general"] == 0
     assert sum(plans[False].values()) == sum(plans[True].values()) == I.grid.n_points
 
 
@@ -597,17 +598,19 @@ def test_gpu_gls_degenerate_set(oracle_lib, kind):
 
 # every way a node can reach a GLS kernel: name -> environment switches (read when the launch plan is built)
 _GLS_ROUTES = {
-    "default": (),                                                        # hex8mf / mfw (row lanes) / block for the rest
+    "default": (),                                                        # cube-node kernel / mfw strips (two-coloured) / the wide kernel / small, quad, block for the boundary
     "cube_kernel_one_wave": ("NIN_HEX8_ONE_WAVE",),                       # round 2's cube-node kernel (one wavefront per SIMD) instead of the two-wave form
     "no_cube_kernel": ("NIN_GLS_NO_GROUP",),                              # cube nodes -> mfw small instantiation
     "mfw_lane_columns": ("NIN_GLS_NO_GROUP", "NIN_MFW_LANE_COLUMNS"),     # the mfw kernel's first form
     "mfw_row_lanes": ("NIN_MFW_NO_STRIPS",),                              # its second form (round 2's default) where the strip form runs now
     "mfw_small_strips": ("NIN_GLS_NO_GROUP", "NIN_MFW_SMALL_STRIPS"),     # the strip form in the small instantiation (wedge / cube nodes)
-    "no_general_kind": ("NIN_GLS_NO_MFW_GENERAL",),                       # general-kind nodes -> block kernel
+    "general_kind": ("NIN_GLS_MFW_GENERAL",),                             # nodes that are not two-coloured: kernels_gls_mfw.hip's general kind where it fits (round 3's default)
+    "no_general_kind": ("NIN_GLS_NO_MFW_GENERAL", "NIN_GLS_NO_MFX"),      # ... -> block kernel
+    "wide_for_two_coloured": ("NIN_GLS_NO_MFW",),                         # Kuhn / wedge nodes through the wide kernel (small ones: the small-node kernel)
     "no_quad_kernel": ("NIN_GLS_NO_QUAD4",),                              # nodes inside a boundary face -> small-node kernel
     "no_small_kernel": ("NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4"),          # boundary nodes -> block kernel (round 2's route)
     "small_where_it_fits": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"),        # the small-node kernel for every node of <= 12 cells and <= 64 rows
-    "block_only": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4"),   # block kernel, 1 / 2 / 4 / 8 wavefronts per node
+    "block_only": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_MFX", "NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4"),   # block kernel, 1 / 2 / 4 / 8 wavefronts per node
     "global_scratch": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_FORCE_GLOBAL"),   # the wave kernel
 }
 
@@ -642,16 +645,18 @@ def test_gpu_gls_degenerate_zero_pivot_column(monkeypatch, kind):
     d = plans["default"]
     assert (d["hex8"] > 0) == (kind in ("hex", "mixed"))
     assert (d["mfw_large"] > 0) == (kind in ("tet", "mixed")) and (d["mfw_small"] > 0) == (kind == "wedge")
-    assert (d["mfw_general"] > 0) == (kind == "mixed")
+    assert (d["mfx"] > 0) == (kind == "mixed") and d["mfw_general"] == 0
+    assert (plans["general_kind"]["mfw_general"] > 0) == (kind == "mixed") and plans["general_kind"]["mfx"] == 0
     assert plans["no_cube_kernel"]["hex8"] == 0 and plans["no_cube_kernel"]["mfw_small"] >= d["hex8"]
-    assert plans["no_general_kind"]["mfw_general"] == 0
+    assert plans["no_general_kind"]["mfw_general"] == 0 and plans["no_general_kind"]["mfx"] == 0
+    assert plans["wide_for_two_coloured"]["mfx"] >= d["mfw_large"] + d["mfx"]
     small = ("small4", "small8", "small12")
     assert sum(d[k] for k in small) > 0 and all(plans["no_small_kernel"][k] == 0 for k in small)
     assert (d["quad4"] > 0 or kind == "tet") and plans["no_quad_kernel"]["quad4"] == 0   # (wedge meshes have quad nodes too: their lateral faces)
     assert sum(plans["no_quad_kernel"][k] for k in small) == sum(d[k] for k in small) + d["quad4"]
     assert sum(plans["small_where_it_fits"][k] for k in small) >= sum(d[k] for k in small) + (d["hex8"] if kind == "hex" else 0)
     for route in ("block_only", "global_scratch"):
-        assert all(plans[route][k] == 0 for k in ("hex8", "mfw_large", "mfw_small", "mfw_general", "quad4") + small), route
+        assert all(plans[route][k] == 0 for k in ("hex8", "mfw_large", "mfw_small", "mfw_general", "mfx", "quad4") + small), route
     assert all(sum(p.values()) == I.grid.n_points for p in plans.values())
 
 
@@ -679,7 +684,8 @@ def test_gpu_gls_fan_permeability(oracle_lib, n):
     # the same nodes through the generic kernels (cube-node kernel off): the bound is a property of the case, not of a kernel
     if n == 32:
         import os
-        for switches in (("NIN_GLS_NO_GROUP",), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4")):
+        for switches in (("NIN_GLS_NO_GROUP",), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"), ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_SMALL"),   # mfw small / small-node / wide kernel
+                         ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_MFX", "NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4")):                              # block kernel
             for sw in switches:
                 os.environ[sw] = "1"
             try:
