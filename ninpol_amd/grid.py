@@ -65,6 +65,7 @@ class Grid:
         self.build_edges = bool(build_edges)
         self._cache = {}
         self._perm_key = None   # fingerprint of the permeability table resident on the device (interpolator.py)
+        self._fields_variable = None   # the variable whose Neumann flags are resident (DevicePlan.ensure_current)
         self._h = ctypes.c_void_p()
         L = _lib.load()
         if build_device is None:   # the native OpenMP builder (csrc/grid_host.cpp)
@@ -165,6 +166,7 @@ class Grid:
     # -- device ------------------------------------------------------------------------------------
     def to_device(self, device=0):
         self._perm_key = None   # a fresh device copy holds no fields
+        self._fields_variable = None   # ... and nobody's Neumann flags: every DevicePlan re-uploads at its next launch
         _lib.check(_lib.load().nin_grid_to_device(self._h, int(device)))
         return self
 

@@ -91,6 +91,9 @@ class _TableCheck:
     def _hash(self):
         self.key = (_table_key(self.perm), _table_key(self.dmag))
 
+    def join(self):
+        self._t.join()
+
     def stale(self):
         self._t.join()
         return self.key != self.grid._perm_key
@@ -418,12 +421,27 @@ class Interpolator:
         if full and idx_t is np.int32:
             # one native call: kernel with `data[j] = weights + neumann_ws[row]` (interpolator.pyx:618) fused, then the
             # device-side csr_matrix + eliminate_zeros (interpolator.pyx:622-624); only the surviving entries cross PCIe
-            check = _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable, speculate=True)
-            indptr, indices, data, nws = _native_interpolate(g, method)
+            # Speculation is adaptive (advisor, round 3): a caller who edits K before every call (nonlinear / time loops) would pay a
+            # wasted run each time -- after a stale check the next calls hash first, and speculation comes back once a call has
+            # found the resident table still current.
+            speculate = not getattr(g, "_perm_edited_last_call", False)
+            key_before = getattr(g, "_perm_key", None)
+            check = _upload_fields(g, method, self.cells_data, self.points_data, self.variable_to_index, variable, speculate=speculate)
+            try:
+                indptr, indices, data, nws = _native_interpolate(g, method)
+            except BaseException:
+                if check is not None:
+                    check.join()                         # never leave the hash thread behind
+                raise
             if check is not None and check.stale():      # the caller's permeability is not the resident one: again, with it
                 del indptr, indices, data, nws
                 check.upload(check.flag)
                 indptr, indices, data, nws = _native_interpolate(g, method)
+                g._perm_edited_last_call = True
+            elif check is not None:
+                g._perm_edited_last_call = False
+            else:                                        # hashed first: was the table edited since the last call?
+                g._perm_edited_last_call = key_before is not None and getattr(g, "_perm_key", None) != key_before
             self._log(f"Interpolation done in {time.time() - t0:.2f} seconds")
             return _wrap_csr(data, indices, indptr, (P, E)), nws
         csr, nws = _run_weights(g, method, self.cells_data, self.points_data, self.variable_to_index, variable,
@@ -515,6 +533,10 @@ class DevicePlan:
         self.interp = interp
         self.variable = variable
         self.grid = g = interp.grid
+        # the tables of THIS mesh (advisor, round 3): a later load_mesh() on the Interpolator replaces interp.grid and its tables;
+        # this plan goes on serving the grid it was made for, with the rows it was made from (in-place edits are still seen)
+        self._cells_data, self._points_data, self._v2i = interp.cells_data, interp.points_data, interp.variable_to_index
+        self._device = interp.device
         self.method = method
         self.method_id = _lib.METHOD_ID[method]
         L = _lib.load()
@@ -529,9 +551,8 @@ class DevicePlan:
     def refresh(self):
         """Upload this plan's field rows from the Interpolator's tables as they are NOW (flags always; permeability and
         diff_mag when their contents changed: a hash of all their bytes)."""
-        I = self.interp
-        _upload_fields(self.grid, self.method, I.cells_data, I.points_data, I.variable_to_index, self.variable,
-                       device=I.device, always_perm=True)
+        _upload_fields(self.grid, self.method, self._cells_data, self._points_data, self._v2i, self.variable,
+                       device=self._device, always_perm=True)
 
     def ensure_current(self):
         if getattr(self.grid, "_fields_variable", None) != self.variable:
@@ -539,9 +560,8 @@ class DevicePlan:
 
     def any_neumann_flag(self):
         """Does any node carry neumann_flag_<variable>?  (neumann_ws is identically zero otherwise.)"""
-        I = self.interp
-        row = I.variable_to_index["points"]["neumann_flag_" + self.variable]
-        return bool(np.any(np.asarray(I.points_data)[row][:self.n_points].astype(np.int64) != 0))
+        row = self._v2i["points"]["neumann_flag_" + self.variable]
+        return bool(np.any(np.asarray(self._points_data)[row][:self.n_points].astype(np.int64) != 0))
 
     def launch(self, csr_data_ptr, neumann_ws_ptr, stream=0, add_neumann=True):
         self.ensure_current()

@@ -458,7 +458,11 @@ class ShardedInterpolator:
         if not fresh:
             sp_.refresh()
         one = False
+        err = None                                   # a bad argument must fail on EVERY rank, before any collective (advisor, round 3)
+        k_known = True
         if sp_.empty:
+            # (an empty rank owns no nodes: it learns the number of fields from the others unless it was given values itself)
+            k_known = values is not None
             k = 1 if values is None or np.ndim(values) == 1 else int(np.shape(values)[0])
             one = values is None or np.ndim(values) == 1
             u = np.zeros((k, 0))
@@ -469,18 +473,26 @@ class ShardedInterpolator:
             else:
                 u = np.asarray(values, dtype=np.float64)
                 n_expected = sp_.local_elems if local_values else self.n_elems
-                if u.shape[-1] != n_expected or u.ndim not in (1, 2):
-                    raise ValueError(f"values must have shape ({n_expected},) or (k, {n_expected}), not {u.shape}.")
-                if not local_values:
+                if u.ndim not in (1, 2) or u.shape[-1] != n_expected:
+                    err = f"values must have shape ({n_expected},) or (k, {n_expected}), not {u.shape}."
+                    u = np.zeros((1, sp_.local_elems))
+                elif not local_values:
                     u = u[..., self.local_cell_ids()]
             one = u.ndim == 1
             u = np.ascontiguousarray(u.reshape(1, -1) if one else u, dtype=np.float64)
             k = u.shape[0]
-        # the number of fields must agree over the group (it sizes the gather); an empty rank learns it from the others
-        kk = torch.tensor([k], dtype=torch.int64, device=self.comm_device)
+        # ONE agreement step before anything else: did any rank reject its argument, and do the ranks that know the number of
+        # fields agree on it (it sizes the gather)?  max over (bad, k, -k): k_min = -max(-k)
         import torch.distributed as dist
+        big = 1 << 40
+        kk = torch.tensor([1 if err else 0, k if k_known else 0, -k if k_known else -big], dtype=torch.int64, device=self.comm_device)
         dist.all_reduce(kk, op=dist.ReduceOp.MAX, group=self.group)
-        k = int(kk[0])
+        any_bad, k_max, k_min = int(kk[0]), int(kk[1]), -int(kk[2])
+        if any_bad:
+            raise ValueError(err or "values were rejected on another rank of the group (every rank raises; no collective was entered).")
+        if k_min != big and k_min != k_max:
+            raise ValueError(f"the ranks disagree about the number of fields: between {k_min} and {k_max} (every rank raises).")
+        k = k_max if k_max > 0 else k
         ut = torch.from_numpy(u).to(self.torch_device) if not sp_.empty else torch.zeros((k, 0), dtype=torch.float64,
                                                                                           device=self.torch_device)
         b = sp_.apply_step(ut)

@@ -51,6 +51,23 @@ class _Reader:
         self.pos = p
         return ln
 
+    def skip_metadata(self):
+        """The body of a METADATA block (VTK / ParaView 9 write one behind an array: INFORMATION <n>, NAME / DATA lines):
+        everything up to the blank line that ends it.  The keyword line itself has been consumed."""
+        while self.pos < len(self.raw):
+            end = self.raw.find(b"\n", self.pos)
+            end = len(self.raw) if end < 0 else end
+            blank = not self.raw[self.pos:end].strip()
+            self.pos = end + 1
+            if blank:
+                break
+
+    def skip_metadata_if_next(self):
+        nxt = self.peek()
+        if nxt is not None and nxt.split()[0].upper() == "METADATA":
+            self.line()
+            self.skip_metadata()
+
     def array(self, count, type_name):
         dt = _DTYPES.get(type_name.lower())
         if dt is None:
@@ -83,11 +100,13 @@ def _read_data_section(r, n, where):
         if ln is None:
             break
         key = ln.split()[0].upper()
-        if key in ("POINT_DATA", "CELL_DATA", "METADATA"):
+        if key in ("POINT_DATA", "CELL_DATA"):
             break
         r.line()
         tok = ln.split()
-        if key == "SCALARS":
+        if key == "METADATA":            # belongs to the array before it: skipped, the section goes on (what meshio's reader does)
+            r.skip_metadata()
+        elif key == "SCALARS":
             name, typ, ncomp = tok[1], tok[2], int(tok[3]) if len(tok) > 3 else 1
             nxt = r.peek()
             if nxt is not None and nxt.split()[0].upper() == "LOOKUP_TABLE":
@@ -100,12 +119,14 @@ def _read_data_section(r, n, where):
             out[tok[1]] = r.array(9 * n, tok[2]).reshape(n, 9)
         elif key == "FIELD":
             for _ in range(int(tok[2])):
+                r.skip_metadata_if_next()            # (a METADATA block may sit between two arrays of a FIELD)
                 head = r.line().split()
                 name, ncomp, ntup, typ = head[0], int(head[1]), int(head[2]), head[3]
                 a = r.array(ncomp * ntup, typ)
                 if ntup != n:
                     raise ValueError(f"legacy VTK: {where} array {name!r} has {ntup} tuples, expected {n}")
                 out[name] = a if ncomp == 1 else a.reshape(ntup, ncomp)
+            r.skip_metadata_if_next()
         elif key in ("LOOKUP_TABLE",):
             r.array(4 * int(tok[2]), "unsigned_char" if r.binary else "float")
         elif key in ("COLOR_SCALARS", "TEXTURE_COORDINATES"):
@@ -167,17 +188,10 @@ def read(filename):
         elif key == "CELL_DATA":
             cell_data.update(_read_data_section(r, int(tok[1]), "CELL_DATA"))
         elif key == "METADATA":
-            while True:                                                        # (information blocks: skipped up to the blank line)
-                p0 = r.pos
-                end = raw.find(b"\n", p0)
-                end = len(raw) if end < 0 else end
-                r.pos = end + 1
-                if not raw[p0:end].strip():
-                    break
-                if r.pos >= len(raw):
-                    break
+            r.skip_metadata()                                                  # (information blocks: skipped up to the blank line)
         elif key == "FIELD":                                                   # a dataset-level field: read and dropped
             for _ in range(int(tok[2])):
+                r.skip_metadata_if_next()
                 h = r.line().split()
                 r.array(int(h[1]) * int(h[2]), h[3])
         else:

@@ -44,3 +44,5 @@ def test_fuzz_case(oracle_lib, case):
         tol = util.WEIGHT_RTOL if meth == "gls" else 1e-14
         assert util.rowscaled_err(w, wo) <= tol, (kind, meth)
         assert util.rowscaled_err(nw, no) <= tol, (kind, meth)
+        # element-wise relative on every entry down to 1e-3 of its row's largest (util.py)
+        assert util.elementwise_err(w, wo) <= util.elementwise_rtol(meth, perm), (kind, meth, perm)

@@ -30,6 +30,7 @@ def test_gpu_matches_golden(case):
         w, nw = I.prepare_interpolator(meth, "u", np.arange(I.grid.n_points))
         tol = util.WEIGHT_RTOL if meth == "gls" else TIGHT
         assert util.rowscaled_err(w, z[f"{meth}_weights"]) <= tol, meth
+        assert util.elementwise_err(w, z[f"{meth}_weights"]) <= util.elementwise_rtol(meth, "FAN" if "fan" in case else "ALH"), meth
         assert util.rowscaled_err(nw, z[f"{meth}_neumann_ws"]) <= tol, meth
         W, nws = I.interpolate("u", meth)
         assert W.shape == (I.grid.n_points, I.grid.n_elems)
@@ -67,6 +68,10 @@ def test_gpu_matches_oracle(oracle_lib, name, mesh, perm, plane):
         Wo, _ = o.interpolate("u", meth)
         W, _ = I.interpolate("u", meth)
         assert util.csr_rowscaled_err(W, Wo.indptr, Wo.indices, Wo.data) <= tol, meth
+        # element-wise relative, every entry down to 1e-3 of its row's largest (util.py)
+        ew = max(util.elementwise_err(w, wo), util.csr_elementwise_err(W, Wo.indptr, Wo.indices, Wo.data))
+        print(f"{name} {meth}: row-scaled {util.rowscaled_err(w, wo):.2e}, element-wise (floor {util.ELEMENTWISE_FLOOR:g}) {ew:.2e}")
+        assert ew <= util.elementwise_rtol(meth, perm), (meth, ew)
 
 
 def test_gpu_target_subset(oracle_lib):

@@ -84,7 +84,7 @@ def test_mixed_mesh_sample_against_oracle(oracle_lib):
         assert util.rowscaled_err(nw[sample], no[sample]) <= tol, meth
 
 
-def test_10m_hex_gls_properties():
+def test_10m_hex_gls_properties(oracle_lib):
     """The north-star workload itself: GLS on 216^3 = 10,077,696 hexahedra; size-independent properties."""
     import ninpol_amd
     mesh = M.hex_mesh(216, jitter=0.15, seed=0)
@@ -94,6 +94,52 @@ def test_10m_hex_gls_properties():
     assert I.grid.n_elems == 10_077_696 and I.grid.n_points == 10_218_313
     W = _check_properties(I, mesh, "gls", linear_exact=False, tol_sum=1e-10)   # ALH tensor: heterogeneous K
     assert W.nnz == 8 * 215 ** 3
+    worst, worst_ew = _oracle_on_node_runs(oracle_lib, mesh, W, runs=8, length=512, seed=11)
+    print(f"216^3 GLS vs the oracle on 8 x 512 nodes: row-scaled {worst:.2e}, element-wise {worst_ew:.2e}")
+    assert worst <= util.WEIGHT_RTOL and worst_ew <= util.ELEMENTWISE_RTOL_GLS, (worst, worst_ew)
+
+
+def _oracle_on_node_runs(oracle_lib, mesh, W, runs, length, seed):
+    """The oracle itself at size: `runs` runs of `length` consecutive nodes, each with the cells around it cut out of the big mesh
+    (partition.extract_submesh: every cell and face of a sampled node is present, so its row is the row of the whole mesh) and
+    mapped back to global column ids.  Returns the worst row-scaled and element-wise errors."""
+    from ninpol_amd.partition import extract_submesh
+    rng = np.random.default_rng(seed)
+    P = mesh.points.shape[0]
+    worst = worst_ew = 0.0
+    for lo in rng.choice(P - length, runs, replace=False):
+        lo = int(lo)
+        sub, pid, cid, owned = extract_submesh(mesh, lo, lo + length)
+        o = oracle_lib.OracleInterpolator("port", threads=16)
+        o.load_mesh(sub)
+        Wo, _ = o.interpolate("u", "gls")
+        Wo = Wo.tocsr()[owned]
+        Wg = W[lo:lo + length]
+        np.testing.assert_array_equal(np.diff(Wg.indptr), np.diff(Wo.indptr))
+        np.testing.assert_array_equal(Wg.indices, cid[Wo.indices])
+        worst = max(worst, util.csr_rowscaled_err(Wg, Wg.indptr, Wg.indices, Wo.data))
+        worst_ew = max(worst_ew, util.csr_elementwise_err(Wg, Wg.indptr, Wg.indices, Wo.data))
+    return worst, worst_ew
+
+
+def test_2m_unstructured_tets_gls_at_size(oracle_lib):
+    """The unstructured mesh of the bench row at size: the Delaunay tetrahedrisation of a jittered 54^3 body-centred cloud
+    (~2 M cells, 324 k nodes, 14 .. 42 cells around an interior node).  The launch plan keeps >= 95 % of the interior nodes off
+    the block kernel; size-independent properties; the oracle on 8 runs of 256 nodes cut out of the big mesh."""
+    import ninpol_amd
+    mesh = M.delaunay_tet_mesh(54, seed=0)
+    M.attach_fields(mesh, "u", perm="ALH")
+    I = ninpol_amd.Interpolator(grid_build="device")
+    I.load_mesh(mesh_obj=mesh)
+    assert I.grid.n_elems > 1_900_000
+    W = _check_properties(I, mesh, "gls", linear_exact=False, tol_sum=1e-10)
+    plan = I.grid.gls_plan()
+    n_int = int(_interior(mesh).sum())
+    one_wave = plan["mfw_large"] + plan["mfw_small"] + plan["mfw_general"] + plan["mfx"] + plan["hex8"]
+    assert one_wave >= 0.95 * n_int, (plan, n_int)
+    worst, worst_ew = _oracle_on_node_runs(oracle_lib, mesh, W, runs=8, length=256, seed=5)
+    print(f"Delaunay 54^3 GLS vs the oracle on 8 x 256 nodes: row-scaled {worst:.2e}, element-wise {worst_ew:.2e}; plan {plan}")
+    assert worst <= util.WEIGHT_RTOL and worst_ew <= util.ELEMENTWISE_RTOL_GLS, (worst, worst_ew)
 
 
 def test_10m_mixed_gls_at_size(oracle_lib):

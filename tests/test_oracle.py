@@ -27,6 +27,7 @@ def test_port_matches_golden(oracle_lib, case):
         else:
             assert util.rowscaled_err(w, z[f"{meth}_weights"]) <= util.WEIGHT_RTOL
             assert util.rowscaled_err(nw, z[f"{meth}_neumann_ws"]) <= util.WEIGHT_RTOL
+            assert util.elementwise_err(w, z[f"{meth}_weights"]) <= util.elementwise_rtol(meth, "FAN" if "fan" in case else "ALH")
         W, _ = o.interpolate("u", meth)
         assert W.shape == (o.grid.n_points, o.grid.n_elems)
         err = util.csr_rowscaled_err(W, z[f"{meth}_indptr"], z[f"{meth}_indices"], z[f"{meth}_data"])

@@ -220,6 +220,48 @@ def test_sharded_apply_and_uneven_blocks(tmp_path, oracle_lib, kind, world, boun
             np.testing.assert_array_equal(z[f"{meth}_v3"], ref)
 
 
+def _worker_bad_values(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from ninpol_amd.partition import ShardedInterpolator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = ShardedInterpolator(device=None, make_interpolator=_OracleCompute)
+        mesh = _make_mesh("hex")
+        P = mesh.points.shape[0]
+        S.load_mesh(mesh, bounds=[0, 0, P // 2, P])          # rank 0 owns nothing
+        u = np.concatenate(mesh.cell_data["u"])
+        got = []
+        # (1) rank 1 alone hands over a wrong shape; (2) ranks 1 and 2 disagree about the number of fields; then a good call
+        for vals in ({1: u[:-3]}, {1: np.stack([u, u]), 2: np.stack([u, u, u])}):
+            try:
+                S.apply("u", "idw", values=vals.get(rank, u))
+                got.append("returned")
+            except ValueError as e:
+                got.append("ValueError: " + str(e)[:40])
+        v, _ = S.apply("u", "idw", values=u)
+        got.append("ok" if v.shape == (P,) else "bad shape")
+        with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+            f.write("\n".join(got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_apply_rejects_bad_values_on_every_rank(tmp_path, oracle_lib):
+    """A wrong `values` shape on ONE rank, or ranks that disagree about the number of fields, must raise ValueError on EVERY rank
+    before any collective is entered -- the other ranks used to walk into the all-gather and hang (advisor finding, round 3) --
+    and the group must still be usable afterwards."""
+    world = 3
+    mp.spawn(_worker_bad_values, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        lines = open(os.path.join(str(tmp_path), f"r{r}.txt")).read().split("\n")
+        assert len(lines) == 3 and lines[0].startswith("ValueError") and lines[1].startswith("ValueError") and lines[2] == "ok", (r, lines)
+
+
 def _worker_alternate(rank, world, port, out_dir):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         if p not in sys.path:

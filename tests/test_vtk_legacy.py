@@ -90,3 +90,62 @@ u 1 2 double
         vtk_legacy.read(str(bad))
     with pytest.raises(ImportError):
         ninpol_amd.Interpolator().load_mesh(filename=str(tmp_path / "mesh.msh"))
+
+
+def test_metadata_blocks_behind_arrays_are_skipped(tmp_path):
+    """VTK / ParaView 9 writers put a METADATA block (INFORMATION ..., ended by a blank line) behind an array -- between two
+    SCALARS of a section, and between / behind the arrays of a FIELD.  The section must go on (advisor finding, round 3)."""
+    from ninpol_amd import vtk_legacy
+    path = tmp_path / "meta.vtk"
+    path.write_text("""# vtk DataFile Version 5.1
+vtk output
+ASCII
+DATASET UNSTRUCTURED_GRID
+POINTS 4 double
+0 0 0 1 0 0 0 1 0 0 0 1
+METADATA
+INFORMATION 1
+NAME L2_NORM_RANGE LOCATION vtkDataArray
+DATA 2 0 1
+
+CELLS 2 4
+OFFSETS vtktypeint64
+0 4
+CONNECTIVITY vtktypeint64
+0 1 2 3
+CELL_TYPES 1
+10
+POINT_DATA 4
+SCALARS a double 1
+LOOKUP_TABLE default
+1 2 3 4
+METADATA
+INFORMATION 0
+
+SCALARS b double 1
+LOOKUP_TABLE default
+5 6 7 8
+FIELD FieldData 2
+c 1 4 double
+9 10 11 12
+METADATA
+INFORMATION 0
+
+d 3 4 double
+1 2 3 4 5 6 7 8 9 10 11 12
+METADATA
+INFORMATION 0
+
+CELL_DATA 1
+FIELD FieldData 1
+permeability 9 1 double
+1 0 0 0 1 0 0 0 1
+METADATA
+INFORMATION 0
+
+""")
+    m = vtk_legacy.read(str(path))
+    assert m.points.shape == (4, 3) and m.cells[0].type == "tetra" and m.cells[0].data.tolist() == [[0, 1, 2, 3]]
+    assert m.point_data["a"].tolist() == [1, 2, 3, 4] and m.point_data["b"].tolist() == [5, 6, 7, 8]
+    assert m.point_data["c"].tolist() == [9, 10, 11, 12] and m.point_data["d"].shape == (4, 3)
+    assert m.cell_data["permeability"][0].shape == (1, 9)
