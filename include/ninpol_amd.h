@@ -195,10 +195,11 @@ const char *nin_kernel_name(int method);
  * counts[6], counts[7], counts[8]: the one-wavefront multifrontal kernel -- two-coloured nodes (large / small
  * instantiation) and the general kind, counts[9], counts[10], counts[11]: the one-wavefront dense kernel for small nodes
  * (at most 4 / 8 / 12 cells; in practice the boundary nodes that are computed), counts[12]: the two-lanes-per-node kernel for
- * the nodes inside a boundary face of a hexahedron mesh, counts[13]: the wide one-wavefront multifrontal kernel (interior nodes
- * of unstructured meshes: up to 16 fronts + 21 dense cells).  (Diagnostics and tests: the reference has one code path,
- * gls.pyx:138-197, for every node.) */
-int nin_gls_plan(const nin_grid *g, int64_t counts[14]);
+ * the nodes inside a boundary face of a hexahedron mesh, counts[13..17]: the wide one-wavefront multifrontal kernel (interior nodes
+ * of unstructured meshes: up to 16 fronts + 21 dense cells) by size class of its dense problem -- at most 96 x 40, 112 x 44,
+ * 128 x 52, 144 x 60, 160 x 64 (rows x columns).  (Diagnostics and tests: the reference has one code path, gls.pyx:138-197,
+ * for every node.) */
+int nin_gls_plan(const nin_grid *g, int64_t counts[18]);
 
 /* Measurement: the FP64 flops one GLS launch performs, kernel by kernel of the launch plan (numbered as in
  * nin_gls_plan): alg[k] = ALGORITHMIC flops of the formulation kernel k runs on its nodes (fronts + dense rest for the
@@ -206,7 +207,7 @@ int nin_gls_plan(const nin_grid *g, int64_t counts[14]);
  * one-wavefront block / global-scratch kernels), ref[k] = the reference's dense dgels on the same nodes (gls.pyx:420-474),
  * computed[k] = the nodes that are computed at all (Dirichlet boundary nodes and nodes outside the parity set get the zero row).
  * Needs nin_fields_set (the Neumann flags decide which boundary nodes are computed). */
-int nin_gls_plan_flops(nin_grid *g, double alg[14], double ref[14], int64_t computed[14]);
+int nin_gls_plan_flops(nin_grid *g, double alg[18], double ref[18], int64_t computed[18]);
 
 #ifdef __cplusplus
 }

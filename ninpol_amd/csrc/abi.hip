@@ -460,7 +460,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
     // ---- GLS launch plan: bin nodes by the size of their least-squares system (classified on the device) ----
     g->node_class.assign((size_t)P, 0);
     std::vector<std::vector<int32_t>> lists(kGlsClasses);
-    std::vector<int32_t> hex8_list, mfw_list[3], small_list[3], quad4_list, mfx_list;
+    std::vector<int32_t> hex8_list, mfw_list[3], small_list[3], quad4_list, mfx_list[DeviceGrid::kMfxLists];
     // debugging switches: keep nodes away from the hex8 kernel (bit 0) / the one-wavefront multifrontal kernel (bit 1)
     const int use_group = (getenv("NIN_GLS_NO_GROUP") == nullptr ? 1 : 0) | (getenv("NIN_GLS_NO_MFW") == nullptr ? 2 : 0) |
                           (getenv("NIN_GLS_NO_MFW_GENERAL") == nullptr ? 4 : 0) |   // (bit 2: the multifrontal kernel's general kind)
@@ -495,7 +495,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         else if (c >= 252 && c <= 254) mfw_list[254 - c].push_back((int32_t)p);
         else if (c >= 249 && c <= 251) small_list[c - 249].push_back((int32_t)p);
         else if (c == 248) quad4_list.push_back((int32_t)p);
-        else if (c == 247) mfx_list.push_back((int32_t)p);
+        else if (c >= 243 && c <= 247) mfx_list[c - 243].push_back((int32_t)p);
         else lists[c].push_back((int32_t)p);
     }
     for (int c = 0; c < kGlsClasses; ++c) {
@@ -551,14 +551,14 @@ int nin_grid_to_device(nin_grid *g, int device) {
             if (launch_mfw_desc(d.v, d.mfw[i].nodes, d.mfw[i].count, d.mfw_desc[i], nullptr)) return fail(NIN_EHIP, "mfw descriptor kernel");
         }
     }
-    {
-        d.mfx.count = (int32_t)mfx_list.size();
+    for (int i = 0; i < DeviceGrid::kMfxLists; ++i) {
+        d.mfx[i].count = (int32_t)mfx_list[i].size();
         const int32_t *lp = nullptr;
-        if (d.mfx.count && (rc = dev_upload(d, &lp, mfx_list))) return rc;
-        d.mfx.nodes = const_cast<int32_t *>(lp);
-        if (d.mfx.count) {   // descriptors of the wide multifrontal kernel, kMfxDescWords (56) words per list entry
-            if ((rc = dev_alloc(d, &d.mfx_desc, (size_t)d.mfx.count * kMfxDescWords))) return rc;
-            if (launch_mfx_desc(d.v, d.mfx.nodes, d.mfx.count, d.mfx_desc, nullptr)) return fail(NIN_EHIP, "mfx descriptor kernel");
+        if (d.mfx[i].count && (rc = dev_upload(d, &lp, mfx_list[i]))) return rc;
+        d.mfx[i].nodes = const_cast<int32_t *>(lp);
+        if (d.mfx[i].count) {   // descriptors of the wide multifrontal kernel, kMfxDescWords (56) words per list entry
+            if ((rc = dev_alloc(d, &d.mfx_desc[i], (size_t)d.mfx[i].count * kMfxDescWords))) return rc;
+            if (launch_mfx_desc(d.v, d.mfx[i].nodes, d.mfx[i].count, d.mfx_desc[i], nullptr)) return fail(NIN_EHIP, "mfx descriptor kernel");
         }
     }
     for (int i = 0; i < 3; ++i) {
@@ -597,7 +597,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         for (int i = 0; i < 3; ++i) cut(kGlsClasses + 1 + i, mfw_list[i]);
         for (int i = 0; i < 3; ++i) cut(kGlsClasses + 4 + i, small_list[i]);
         cut(kGlsClasses + 7, quad4_list);
-        cut(kGlsClasses + 8, mfx_list);
+        for (int i = 0; i < DeviceGrid::kMfxLists; ++i) cut(kGlsClasses + 8 + i, mfx_list[i]);
         const char *mn = getenv("NIN_E2E_MIN_NODES");                                // (tests: the pipeline on small meshes too)
         d.chunkable = P >= (mn ? atoll(mn) : 64 * 1024) && P >= 64 * K && getenv("NIN_E2E_NO_PIPELINE") == nullptr;   // small meshes: one piece
     }
@@ -703,7 +703,8 @@ static int launch_gls_but_cube(DeviceGrid &d, int add_neumann, double *out, doub
     for (int i = 0; i < 3 && !rc; ++i)
         if (on(9 + i)) rc = launch_gls_small(d.v, d.small[i].nodes, d.small[i].count, i, add_neumann, out, nws, stream);
     if (!rc && on(12)) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, out, nws, stream);
-    if (!rc && on(13)) rc = launch_gls_mfx(d.v, d.mfx.nodes, d.mfx_desc, d.mfx.count, add_neumann, out, nws, d.gls_queue + 8, stream);   // (work counter: int 8)
+    for (int i = 0; i < DeviceGrid::kMfxLists && !rc; ++i)   // (work counters: ints 8 .. 12)
+        if (on(13 + i)) rc = launch_gls_mfx(d.v, d.mfx[i].nodes, d.mfx_desc[i], d.mfx[i].count, i, add_neumann, out, nws, d.gls_queue + 8 + i, stream);
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         if ((c == kGlsClasses - 1 && d.side_pending) || !on(c)) continue;
         rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, out, nws, stream);
@@ -749,14 +750,14 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     HIP_TRY(hipMemsetAsync(dev_csr_data, 0, (size_t)d.nnz_e * 8, stream));
     HIP_TRY(hipMemsetAsync(dev_neumann_ws, 0, (size_t)P * 8, stream));
     if (n_targets == 0) return NIN_OK;
-    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 9 : 1);
+    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 8 + DeviceGrid::kMfxLists : 1);
     for (int64_t i = 0; i < n_targets; ++i) {
         int c = method == NIN_METHOD_GLS ? g->node_class[targets[i]] : 0;
         if (c == 255) c = kGlsClasses;   // the hex8 kernel's class
         else if (c >= 252 && c <= 254) c = kGlsClasses + 1 + (254 - c);   // the one-wavefront multifrontal kernel, kind 0 / 1 / 2
         else if (c >= 249 && c <= 251) c = kGlsClasses + 4 + (c - 249);   // the small-node kernel, kind 0 / 1 / 2
         else if (c == 248) c = kGlsClasses + 7;                           // the quad-node kernel
-        else if (c == 247) c = kGlsClasses + 8;                           // the wide multifrontal kernel
+        else if (c >= 243 && c <= 247) c = kGlsClasses + 8 + (c - 243);   // the wide multifrontal kernel, by size class
         lists[c].push_back((int32_t)targets[i]);
     }
     // one device buffer for all class lists, filled before the first launch: a per-class allocate / copy / free
@@ -773,7 +774,9 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     const size_t n_hex8 = method == NIN_METHOD_GLS ? lists[kGlsClasses].size() : 0;   // + 4 descriptor words per cube node
     const size_t n_mfw = method == NIN_METHOD_GLS ? lists[kGlsClasses + 1].size() + lists[kGlsClasses + 2].size() + lists[kGlsClasses + 3].size() : 0;   // + kMfwDescWords per node of the multifrontal kernel (the three lists are adjacent)
     const size_t n_quad4 = method == NIN_METHOD_GLS ? lists[kGlsClasses + 7].size() : 0;   // + 2 descriptor words per quad node
-    const size_t n_mfx = method == NIN_METHOD_GLS ? lists[kGlsClasses + 8].size() : 0;     // + kMfxDescWords per node of the wide multifrontal kernel
+    size_t n_mfx = 0;                                                                      // + kMfxDescWords per node of the wide multifrontal kernel (its lists are adjacent)
+    if (method == NIN_METHOD_GLS)
+        for (int i = 0; i < DeviceGrid::kMfxLists; ++i) n_mfx += lists[kGlsClasses + 8 + i].size();
     HIP_TRY(hipMalloc((void **)&dl0, (flat.size() + 4 * n_hex8 + kMfwDescWords * n_mfw + 2 * n_quad4 + kMfxDescWords * n_mfx) * 4));
     int32_t *ddesc = dl0 + flat.size();
     uint32_t *dmfw = reinterpret_cast<uint32_t *>(ddesc + 4 * n_hex8);
@@ -808,7 +811,9 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_hex8(d, dl, ddesc, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
-        else if ((int)c == kGlsClasses + 8) rc = launch_gls_mfx(d.v, dl, dmfx, cnt, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue + 8, stream);
+        else if ((int)c >= kGlsClasses + 8)
+            rc = launch_gls_mfx(d.v, dl, dmfx + kMfxDescWords * (first[c] - first[kGlsClasses + 8]), cnt, (int)c - kGlsClasses - 8, add_neumann, dev_csr_data,
+                                dev_neumann_ws, d.gls_queue + 8 + ((int)c - kGlsClasses - 8), stream);
         else if ((int)c == kGlsClasses + 7) rc = launch_gls_quad4(d.v, dl, dquad, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c >= kGlsClasses + 4) rc = launch_gls_small(d.v, dl, cnt, (int)c - kGlsClasses - 4, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c > kGlsClasses)
@@ -965,9 +970,9 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
         const int32_t b = d.chunk_off[kGlsClasses + 7][k], n = d.chunk_off[kGlsClasses + 7][k + 1] - b;
         if (n > 0) rc = launch_gls_quad4(d.v, d.quad4.nodes + b, d.quad4_desc + 2 * (size_t)b, n, 1, out, nws, stream);
     }
-    if (!rc) {
-        const int32_t b = d.chunk_off[kGlsClasses + 8][k], n = d.chunk_off[kGlsClasses + 8][k + 1] - b;
-        if (n > 0) rc = launch_gls_mfx(d.v, d.mfx.nodes + b, d.mfx_desc + (size_t)kMfxDescWords * b, n, 1, out, nws, d.gls_queue + 8, stream);
+    for (int i = 0; i < DeviceGrid::kMfxLists && !rc; ++i) {
+        const int32_t b = d.chunk_off[kGlsClasses + 8 + i][k], n = d.chunk_off[kGlsClasses + 8 + i][k + 1] - b;
+        if (n > 0) rc = launch_gls_mfx(d.v, d.mfx[i].nodes + b, d.mfx_desc[i] + (size_t)kMfxDescWords * b, n, i, 1, out, nws, d.gls_queue + 8 + i, stream);
     }
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         const int32_t b = d.chunk_off[c][k], n = d.chunk_off[c][k + 1] - b;
@@ -1246,7 +1251,7 @@ double dense_flops(int64_t ne, int64_t n_if, int64_t n_nb) {
 double dgels_flops(double m, double n, double nrhs) { return 2 * m * n * n - 2 * n * n * n / 3 + nrhs * (4 * m * n - 2 * n * n) + nrhs * n * n; }
 }  // namespace
 
-int nin_gls_plan_flops(nin_grid *g, double alg[14], double ref[14], int64_t computed[14]) {
+int nin_gls_plan_flops(nin_grid *g, double alg[18], double ref[18], int64_t computed[18]) {
     if (!g || !alg || !ref || !computed) return fail(NIN_EINVAL, "NULL argument");
     DeviceGrid &d = g->d;
     HostGrid &h = g->h;
@@ -1254,7 +1259,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[14], double ref[14], int64_t comp
     if (!d.fields_set || !d.flag_staging) return fail(NIN_ESTATE, "nin_fields_set has not been called (the Neumann flags decide which boundary nodes are computed)");
     if (h.ensure(A_ESUP_PTR | A_ESUP | A_FSUP_PTR | A_FSUP | A_ESUF)) return fail(NIN_EHIP, "mirroring the connectivity failed");
     HIP_TRY(hipSetDevice(d.device));
-    for (int k = 0; k < 14; ++k) { alg[k] = ref[k] = 0.0; computed[k] = 0; }
+    for (int k = 0; k < 18; ++k) { alg[k] = ref[k] = 0.0; computed[k] = 0; }
     const int64_t P = h.n_points;
     // (F, D, free faces) of the nodes of the multifrontal kernels: from their descriptors
     std::vector<uint32_t> fdq((size_t)P, 0u);
@@ -1269,10 +1274,11 @@ int nin_gls_plan_flops(nin_grid *g, double alg[14], double ref[14], int64_t comp
     };
     for (int i = 0; i < 3; ++i)
         if (read_desc(d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, kMfwDescWords, 24)) return fail(NIN_EHIP, "reading the descriptors back failed");
-    if (read_desc(d.mfx.nodes, d.mfx_desc, d.mfx.count, kMfxDescWords, 0)) return fail(NIN_EHIP, "reading the descriptors back failed");
+    for (int i = 0; i < DeviceGrid::kMfxLists; ++i)
+        if (read_desc(d.mfx[i].nodes, d.mfx_desc[i], d.mfx[i].count, kMfxDescWords, 0)) return fail(NIN_EHIP, "reading the descriptors back failed");
     for (int64_t p = 0; p < P; ++p) {
         const int c = g->node_class[p];
-        const int k = c == 255 ? 5 : (c >= 252 && c <= 254) ? 6 + (254 - c) : (c >= 249 && c <= 251) ? 9 + (c - 249) : c == 248 ? 12 : c == 247 ? 13 : c;
+        const int k = c == 255 ? 5 : (c >= 252 && c <= 254) ? 6 + (254 - c) : (c >= 249 && c <= 251) ? 9 + (c - 249) : c == 248 ? 12 : (c >= 243 && c <= 247) ? 13 + (c - 243) : c;
         const int fl = d.flag_staging[p];
         if ((fl & 1) && !(fl & 2)) continue;                   // a Dirichlet boundary node: the zero row, nothing computed (gls.pyx:165-166)
         const int64_t eb = h.esup_ptr[p], ne = h.esup_ptr[p + 1] - eb, fb = h.fsup_ptr[p], nf = h.fsup_ptr[p + 1] - fb;
@@ -1287,7 +1293,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[14], double ref[14], int64_t comp
         ++computed[k];
         ref[k] += dgels_flops((double)(ne + 3 * nf + n_nb), (double)(3 * ne + 1), (double)(ne + (n_nb ? 1 : 0)));
         if (k == 5) alg[k] += multifrontal_flops(4, 4, 12, 0);
-        else if ((k >= 6 && k <= 8) || k == 13) {
+        else if ((k >= 6 && k <= 8) || k >= 13) {
             const uint32_t w = fdq[p];
             alg[k] += multifrontal_flops(w & 255u, (w >> 8) & 255u, n_if, (w >> 16) & 255u);
         } else if (k == 12) {
@@ -1330,7 +1336,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[14], double ref[14], int64_t comp
     return NIN_OK;
 }
 
-int nin_gls_plan(const nin_grid *g, int64_t counts[14]) {
+int nin_gls_plan(const nin_grid *g, int64_t counts[18]) {
     if (!g || !counts) return fail(NIN_EINVAL, "NULL argument");
     if (g->d.device < 0 || g->d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
     for (int c = 0; c < kGlsClasses; ++c) counts[c] = g->d.gls[c].count;
@@ -1340,7 +1346,7 @@ int nin_gls_plan(const nin_grid *g, int64_t counts[14]) {
     counts[8] = g->d.mfw[2].count;
     for (int i = 0; i < 3; ++i) counts[9 + i] = g->d.small[i].count;
     counts[12] = g->d.quad4.count;
-    counts[13] = g->d.mfx.count;
+    for (int i = 0; i < DeviceGrid::kMfxLists; ++i) counts[13 + i] = g->d.mfx[i].count;
     return NIN_OK;
 }
 

@@ -83,8 +83,11 @@ struct DeviceGrid {
     int32_t *hex8_desc = nullptr;   // [4 * hex8.count] lane descriptors (hex8_desc.hpp)
     GlsClass mfw[3];   // kernels_gls_mfw.hip (mfw_desc.hpp): two-coloured nodes large (Kuhn tetrahedra) / small (wedges), general kind
     uint32_t *mfw_desc[3] = {nullptr, nullptr, nullptr};   // [kMfwDescWords * mfw[i].count] descriptor words
-    GlsClass mfx;      // kernels_gls_mfx.hip (mfx_desc.hpp): interior nodes of unstructured meshes, up to 16 fronts + 21 dense cells
-    uint32_t *mfx_desc = nullptr;   // [kMfxDescWords * mfx.count] descriptor words
+    // kernels_gls_mfx.hip (mfx_desc.hpp): interior nodes of unstructured meshes, up to 16 fronts + 21 dense cells, one list per size
+    // class of the dense problem (6 x 10, 7 x 11, 8 x 13, 9 x 15, 10 x 16 tiles)
+    static constexpr int kMfxLists = 5;
+    GlsClass mfx[kMfxLists];
+    uint32_t *mfx_desc[kMfxLists] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [kMfxDescWords * mfx[c].count] descriptor words
     const int32_t *noncube_nodes = nullptr;   // every node the cube-node kernel does not take (the fused apply's list kernel)
     int32_t noncube_count = 0;
     bool noncube_nodes_ready = false;
@@ -112,10 +115,10 @@ struct DeviceGrid {
     bool side_pending = false;
     // interpolate()'s pipeline (abi.hip, interpolate_chunked): the node range is cut into kE2eChunks pieces at multiples of 64 nodes;
     // every GLS list is ascending, so a piece is a sub-range of each: chunk_off[list][k] .. chunk_off[list][k + 1]
-    // (lists 0 .. kGlsClasses - 1: the block kernel's classes, then the cube-node kernel, the three mfw kinds, the three small kinds, the quad nodes, the wide multifrontal kernel)
+    // (lists 0 .. kGlsClasses - 1: the block kernel's classes, then the cube-node kernel, the three mfw kinds, the three small kinds, the quad nodes, the wide multifrontal kernel's five size classes)
     static constexpr int kE2eChunks = 4;
     int32_t chunk_node[kE2eChunks + 1] = {0, 0, 0, 0, 0};
-    int32_t chunk_off[kGlsClasses + 9][kE2eChunks + 1] = {};
+    int32_t chunk_off[kGlsClasses + 8 + kMfxLists][kE2eChunks + 1] = {};
     bool chunkable = false;
     bool gls_too_large = false;     // some node's system has more rows than the scratch kernel handles (1024)
 };

@@ -583,7 +583,8 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
     // interior nodes of unstructured meshes: more cells than the kinds above hold, no two-colouring (kernels_gls_mfx.hip, mfx_desc.hpp)
     if ((use_group & 32) && !force_global && nbf == 0 && ne <= kMfxMaxCells && !small_fits) {
         uint32_t w[kMfxDescWords];
-        if (mfx_descriptor(g, (int32_t)p, w)) { node_class[p] = 247; return; }
+        const int k = mfx_descriptor(g, (int32_t)p, w);   // 1 + the size class of its dense problem
+        if (k > 0) { node_class[p] = (uint8_t)(243 + k - 1); return; }
     }
     // nodes inside a boundary face of a hexahedron mesh: two lanes per node (kernels_gls_quad4.hip)
     if ((use_group & 16) && !force_global && ne == 4 && nf == 8 && nbf == 4 && g.dim == 3) {

@@ -1,17 +1,19 @@
 // kernels_gls_mfx.hip -- GLS weights of interior nodes of UNSTRUCTURED meshes (mfx_desc.hpp: up to 16 fronts + 21 dense cells,
-// 16 free faces; a Delaunay tetrahedrisation has 14 .. 40 cells around a node), gfx950: one wavefront per node, ONE wavefront per
-// SIMD -- the dense problem, up to 160 x 64, lives in 160 16-row x 4-column tiles of the unified register file (the matrix unit
-// reads and writes the accumulation registers directly, so the tiles never pass through the vector registers).
+// 16 free faces; a Delaunay tetrahedrisation has 14 .. 40 cells around a node and no two-colouring), gfx950: one wavefront per
+// node, the dense problem -- up to 160 x 64 -- in 16-row x 4-column tiles of the unified register file: at ONE wavefront per SIMD
+// the 512 registers of a lane hold up to 160 tiles (the matrix unit reads and writes the accumulation registers directly).
 //
 // The system and phase 1 are kernels_gls_mfw.hip's (gls.pyx:252-356; fronts = cells with exactly 3 faces at the node that share
-// no face, four lanes per front).  What differs is the dense phase.  kernels_gls_mfw.hip's strip form unrolls one body per
-// generation of panels and per node size class (its 96 x 37 Kuhn problem: 5 bodies, 60 tiles, two wavefronts per SIMD); at
-// 160 x 64 that would be 8 bodies of ~60 KB of code sweeping blocks of zeros for every node smaller than the largest.  Here ONE
-// body serves every panel of every node: which tiles and column blocks take part is decided by wave-uniform branches (the pivot
-// tile index, the number of live row tiles and of live trailing column blocks are scalars), so the work is proportional to the
-// node's own size -- a 96 x 37 node executes what the Kuhn instantiation executes -- and the code stays inside the instruction
-// cache.  Same mathematics as dgels on the reference's matrix: a blocked Householder QR (compact WY, panels of four) under a
-// column / row order that exposes the zeros.
+// no face, four lanes per front).  The dense phase is mfw_strips.hpp's strip form (blocked Householder QR, compact WY panels of
+// four, the FP64 matrix unit as the cross-lane adder), instantiated per SIZE CLASS -- (6, 10), (7, 11), (8, 13), (9, 15), (10, 16)
+// row tiles x column blocks -- each class its own kernel and its own list of the launch plan: straight-line code of the class's
+// size.  (Round 4 first built ONE body for every panel of every node, driven by wave-uniform branches so that the work followed
+// the node's own size -- mfx_strips.hpp, kept for tools/test_xstrip.hip: a lone wavefront pays ~50 cycles for every taken branch,
+// and that form is 1.9 x slower on the same 118 x 48 problem than the unrolled class it falls into.  And a lone wavefront cannot
+// overlap anything: tools/micro_overlap.hip -- an FP64 MFMA issued into the shadow of a dependent FP64 chain costs the SUM of the
+// two, so look-ahead between the panel factorisation and the trailing update buys nothing here.)  The smallest class, 60 tiles =
+// the Kuhn problem's size, runs at two wavefronts per SIMD.  Same mathematics as dgels on the reference's matrix: a Householder QR
+// under a column / row order that exposes the zeros.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -21,7 +23,6 @@
 #include "launch.hpp"
 #include "mfw_strips.hpp"
 #include "mfx_desc.hpp"
-#include "mfx_strips.hpp"
 
 namespace nin {
 
@@ -29,29 +30,29 @@ namespace {
 
 using namespace glsmath;
 using namespace mfwstrips;
-using namespace mfxstrips;
 
-// Staging area (phase 1 -> tiles; it lies under R): every row of the dense problem as 13 doubles
+// Staging area (phase 1 -> tiles; it lies under R): row r of the dense problem as 13 doubles at 13 r,
 //     [0 0 0 | cell 1 (3) | cell 2 (3) | cell 3 (3) | c]
 // so that the entry of a column whose cell has code k in the row (0: not one of the row's cells) is at 3 k + component -- code 0
 // reads the zeros in front, no select.  A front's 7 fill rows have 3 cells, a free face's 3 rows 2, a dense cell's row 1 (c = 1).
-constexpr int XROW = 13, XSTAGE_F = 7 * XROW, XSTAGE_Q = 3 * XROW;
-constexpr int XNP = 3 * kMfxMaxDense;                // pivot rows
-constexpr int X_CD = kMfxMaxFronts * XSTAGE_F;       // the dense cells' rows
-constexpr int X_FS = X_CD + kMfxMaxDense * XROW;     // the free faces' rows
-constexpr int X_Y = XNP * XRP + 1, X_W = X_Y + 64, X_Z = X_W + 40, X_DESC = X_Z + 2,
-              X_PER_WAVE = X_DESC + kMfxDescWords / 2;
-static_assert(X_FS + kMfxMaxFree * XSTAGE_Q <= XNP * XRP, "the staging area lies under R");
-static_assert(16 * XQ >= kMfxMaxRows && 4 * XCB >= XNP + 1 && (X_DESC & 1) == 0, "tiles");
+// Rows: 7 f + i (fill row i of front f), 7 F + d (dense cell d), 7 F + D + 3 q + k (row k of free face q).
+constexpr int XROW = 13;
+template <int TQ, int TCB>
+struct XDims {
+    static constexpr int RP = 4 * TCB + 1;               // pitch of R in LDS (odd: lane = row reads are conflict-free)
+    static constexpr int NP = 4 * TCB - 1;               // pivot rows at most (nc <= 4 TCB - 1: c has a column)
+    static constexpr int STAGE = 16 * TQ * XROW, RSZ = NP * RP;
+    static constexpr int MAIN = ((STAGE > RSZ ? STAGE : RSZ) + 1) & ~1;
+    static constexpr int Y = MAIN, W = Y + 64, Z = W + 40, DESC = Z + 2, PER_WAVE = DESC + kMfxDescWords / 2;
+    static constexpr int WAVES = TQ * TCB <= 60 ? 2 : 1;   // wavefronts per SIMD (60 tiles: the registers of half a SIMD lane hold them)
+};
 
-// The dense phase of one node: gather the rows from the staging area into TQ x TCB tiles (16 rows x 4 columns each), factor.
-// SINGLE: the one-body form (xstrip_factor: wave-uniform branches, work proportional to the node -- and ~50 cycles a taken
-// branch); otherwise mfw_strips.hpp's unrolled strip_factor<TQ, TCB>, straight-line, which sweeps the whole class size.
-template <int TQ, int TCB, bool SINGLE>
+// The dense phase of one node: gather the rows from the staging area into TQ x TCB tiles (16 rows x 4 columns each) and factor
+// (mfw_strips.hpp's unrolled strip_factor<TQ, TCB>: straight-line, sweeps the whole class size).
+template <int TQ, int TCB>
 __device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, int nc, int nrows, int F, int D, int nfree, int lane) {
-    static_assert(!SINGLE || (TQ == XQ && TCB == XCB), "the single-body form has one size");
+    using Dm = XDims<TQ, TCB>;
     const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
-    const int nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
     double C[TQ][TCB];
     // code(sd) = 1 + the index of dense slot sd among the row's cells (0: not one of them), two bits per slot; a front's
     // table is made once (lane f) and shuffled
@@ -62,24 +63,24 @@ __device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, in
         tlo = lane < F ? (uint32_t)t : 0u;
         thi = lane < F ? (uint32_t)(t >> 32) : 0u;
     }
-    // per tile row q, this lane's row: rtl / rth = the 2-bit codes of its cells' slots (slots 0 .. 15 / 16 .. 20), rbz = the
-    // byte address of the row in the staging area (the lanes of rows that do not exist read front 0's zeros), rbc = of its c
+    // per tile row q, this lane's row: rtl / rth = the 2-bit codes of its cells' slots (slots 0 .. 15 / 16 .. 20), rbz = the byte
+    // address of the row in the staging area (a row beyond the node's: row 0, whose codes are all zero then), rbc = of its c
     uint32_t rtl[TQ], rth[TQ], rbz[TQ], rbc[TQ];
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
         const int row = 16 * q + 4 * sb + si;
         const bool fill = row < 7 * F;
-        const int f = fill ? (row * 9363) >> 16 : 0, i = row - 7 * f, d = row - 7 * F, x = d - D;
+        const int f = fill ? (row * 9363) >> 16 : 0, d = row - 7 * F, x = d - D;
         const bool cell = d >= 0 && d < D, fre = x >= 0 && x < 3 * nfree;
-        const int qf = fre ? (x * 43) >> 7 : 0, k3 = x - 3 * qf;
+        const int qf = fre ? (x * 43) >> 7 : 0;
         const uint32_t flo = (uint32_t)__shfl((int)tlo, f), fhi = (uint32_t)__shfl((int)thi, f);
         const uint32_t fw = dl[kMfxFree0 + qf];
         const uint64_t qt = (1ull << (2 * ((fw >> 6) & 31u))) | (2ull << (2 * ((fw >> 11) & 31u)));
         rtl[q] = fill ? flo : cell ? (d < 16 ? 1u << (2 * d) : 0u) : fre ? (uint32_t)qt : 0u;
         rth[q] = fill ? fhi : cell ? (d >= 16 ? 1u << (2 * (d - 16)) : 0u) : fre ? (uint32_t)(qt >> 32) : 0u;
-        const int base = fill ? f * XSTAGE_F + i * XROW : cell ? X_CD + XROW * d : fre ? X_FS + XSTAGE_Q * qf + XROW * k3 : 0;
-        rbz[q] = 8u * (uint32_t)base;
-        rbc[q] = (fill || cell || fre) ? 8u * (uint32_t)(base + 12) : 8u * (uint32_t)X_Z;
+        const bool have = row < nrows;
+        rbz[q] = have ? 8u * XROW * (uint32_t)row : 0u;
+        rbc[q] = have ? 8u * (XROW * (uint32_t)row + 12u) : 8u * (uint32_t)Dm::Z;
     }
     const char *const Rb = reinterpret_cast<const char *>(Rm);
     const int cbc = nc >> 2;                             // c: column nc & 3 of block cbc
@@ -97,35 +98,29 @@ __device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, in
         const uint32_t cmask = (cb == cbc && is_c_lane) ? 0xFFFFFFFFu : 0u;   // this lane's column of this block is c
 #pragma unroll
         for (int q = 0; q < TQ; ++q) {
-            if (!SINGLE || (q < nq && cb < ncb)) {     // (straight-line in the class instantiations: rows / columns beyond the node read zeros)
-                const uint32_t code = ((cb < 12 ? rtl[q] : rth[q]) >> sh) & 3u;
-                const uint32_t a = rbz[q] + 24u * code + tt8;
-                C[q][cb] = *reinterpret_cast<const double *>(Rb + ((rbc[q] & cmask) | (a & ~cmask)));
-            } else {
-                C[q][cb] = 0.0;
-            }
+            const uint32_t code = ((cb < 12 ? rtl[q] : rth[q]) >> sh) & 3u;
+            const uint32_t a = rbz[q] + 24u * code + tt8;
+            C[q][cb] = *reinterpret_cast<const double *>(Rb + ((rbc[q] & cmask) | (a & ~cmask)));
         }
     }
     wave_lds_sync();          // the staging area is R's from here on
-    if constexpr (SINGLE) {
-        XStamps ST;
-        return xstrip_factor(C, nc, nrows, lane, Rm, ST);
-    } else {
-        SubStamps ST;
-        return strip_factor<TQ, TCB>(C, nc, lane, Rm, XRP, ST);
-    }
+    SubStamps ST;
+    return strip_factor<TQ, TCB>(C, nc, lane, Rm, Dm::RP, ST);
 }
 
-__global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32_t *__restrict__ nodes, const uint32_t *__restrict__ desc,
-                                                        int32_t count, int add_neumann, double *__restrict__ out,
-                                                        double *__restrict__ nws, int32_t *__restrict__ queue) {
-    __shared__ double Rm[X_PER_WAVE];
+template <int TQ, int TCB>
+__global__ __launch_bounds__(64, (XDims<TQ, TCB>::WAVES)) void nin_gls_mfx_kernel(GridView g, const int32_t *__restrict__ nodes,
+                                                                                 const uint32_t *__restrict__ desc, int32_t count,
+                                                                                 int add_neumann, double *__restrict__ out,
+                                                                                 double *__restrict__ nws, int32_t *__restrict__ queue) {
+    using Dm = XDims<TQ, TCB>;
+    constexpr int RP = Dm::RP;
+    __shared__ double Rm[Dm::PER_WAVE];
     const int lane = threadIdx.x;
-    double *const yb = Rm + X_Y, *const wbuf = Rm + X_W;
-    uint32_t *const dl = reinterpret_cast<uint32_t *>(Rm + X_DESC);
+    double *const yb = Rm + Dm::Y, *const wbuf = Rm + Dm::W;
+    uint32_t *const dl = reinterpret_cast<uint32_t *>(Rm + Dm::DESC);
     const uint8_t *const slotpos = reinterpret_cast<const uint8_t *>(dl + kMfxSlotTable);
-    if (lane == 0) { Rm[X_Z] = 0.0; Rm[X_Z + 1] = 1.0; }
-    const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
+    if (lane == 0) { Rm[Dm::Z] = 0.0; Rm[Dm::Z + 1] = 1.0; }
 
     auto ticket = [&]() -> int32_t {
         int32_t v = 0;
@@ -210,7 +205,7 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
             for (int t = 0; t < 3; ++t) u[t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));
             if (fq < F) {
                 // the c lane writes c and the row's three zeros, the others their cell's three entries
-                double *stg = Rm + fq * XSTAGE_F + (jq == 0 ? 0 : 3 + 3 * my);
+                double *stg = Rm + 7 * XROW * fq + (jq == 0 ? 0 : 3 + 3 * my);   // rows 7 f .. 7 f + 6 of the dense problem
 #pragma unroll
                 for (int r = 0; r < 7; ++r) {
                     stg[r * XROW + 0] = jq == 0 ? 0.0 : B[3 + r][0];
@@ -239,7 +234,7 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
             eta = db > eta ? db : eta;
             const double tj = face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
             const double *Ka = g.perm + 9 * (size_t)ca_, *Kb = g.perm + 9 * (size_t)cb_;
-            double *fs = Rm + X_FS + XSTAGE_Q * lane;
+            double *fs = Rm + XROW * (7 * F + D + 3 * lane);    // rows 7 F + D + 3 q .. + 2
             const double Tv[3] = {T0, T1, T2}, Uv[3] = {tj * U0, tj * U1, tj * U2};
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
@@ -255,7 +250,7 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
         }
         // the dense cells' rows: (x_K - x_v) on the cell's own columns, c = 1
         if (lane < D) {
-            double *cd = Rm + X_CD + XROW * lane;
+            double *cd = Rm + XROW * (7 * F + lane);
             cd[0] = 0.0; cd[1] = 0.0; cd[2] = 0.0;
             cd[3] = dod[0]; cd[4] = dod[1]; cd[5] = dod[2];
             cd[12] = 1.0;
@@ -264,26 +259,14 @@ __global__ __launch_bounds__(64) void nin_gls_mfx_kernel(GridView g, const int32
 
         const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
         const int nrows = 7 * F + D + 3 * nfree;
-        // ---- the dense problem in 16 x 4 tiles: rows = the fronts' 7 fill rows each, the D cell rows, 3 rows per free face.  One
-        //      straight-line instantiation per size class (a lone wavefront pays ~50 cycles for every taken branch: the single-body
-        //      form with wave-uniform branches, xstrip_factor, is 1.9 x slower on the same problem -- tools/test_xstrip.hip)
-        double rr;
-#if defined(NIN_MFX_SINGLE_BODY)
-        rr = dense_phase<XQ, XCB, true>(Rm, dl, nc, nrows, F, D, nfree, lane);
-#else
-        if (nrows <= 96 && nc < 40) rr = dense_phase<6, 10, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
-        else if (nrows <= 112 && nc < 44) rr = dense_phase<7, 11, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
-        else if (nrows <= 128 && nc < 52) rr = dense_phase<8, 13, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
-        else if (nrows <= 144 && nc < 60) rr = dense_phase<9, 15, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
-        else rr = dense_phase<XQ, XCB, false>(Rm, dl, nc, nrows, F, D, nfree, lane);
-#endif
+        const double rr = dense_phase<TQ, TCB>(Rm, dl, nc, nrows, F, D, nfree, lane);
         wave_lds_sync();
         // ---- R y = (Q^T c)(0:nc) by columns: lane = row ------------------------------------------------------------------
         {
             const int li = lane < nc ? lane : 0;
-            double ct = lane < nc ? Rm[li * XRP + nc] : 0.0;
-            const double ri = fast_rcp(Rm[li * XRP + li]);
-            const double *Rl = Rm + li * XRP;
+            double ct = lane < nc ? Rm[li * RP + nc] : 0.0;
+            const double ri = fast_rcp(Rm[li * RP + li]);
+            const double *Rl = Rm + li * RP;
             int kb = (nc - 1) & ~3;
             double c4[4], n4[4];
 #pragma unroll
@@ -357,13 +340,24 @@ int launch_mfx_desc(const GridView &g, const int32_t *nodes, int32_t count, uint
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int add_neumann, double *out,
+// `cls`: the size class of every node of the list (mfx_desc.hpp: mfx_size_class)
+int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int cls, int add_neumann, double *out,
                    double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
+    if (cls < 0 || cls >= kMfxClasses) return -1;
     int64_t blocks = count;
-    const int64_t cap = 4 * 256;   // persistent: one wavefront per SIMD (the whole register file of a SIMD lane belongs to one node)
+    // persistent: one wavefront per workgroup, one (class 0: two) per SIMD -- the register file of a SIMD lane belongs to one (two) node(s)
+    const int64_t cap = 4 * 256 * (cls == 0 ? 2 : 1);
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(nin_gls_mfx_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, desc, count, add_neumann, out, nws, queue);
+#define NIN_MFX_LAUNCH(TQ, TCB)                                                                                                      \
+    hipLaunchKernelGGL((nin_gls_mfx_kernel<TQ, TCB>), dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, desc, count, add_neumann, out, \
+                       nws, queue)
+    if (cls == 0) NIN_MFX_LAUNCH(6, 10);
+    else if (cls == 1) NIN_MFX_LAUNCH(7, 11);
+    else if (cls == 2) NIN_MFX_LAUNCH(8, 13);
+    else if (cls == 3) NIN_MFX_LAUNCH(9, 15);
+    else NIN_MFX_LAUNCH(10, 16);
+#undef NIN_MFX_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

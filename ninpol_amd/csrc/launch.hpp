@@ -44,7 +44,8 @@ const char *kernel_name_gls_mfw();
 // cells, one wavefront per SIMD, the tiles in the accumulation registers); `desc` = kMfxDescWords (56) words per list entry
 // (mfx_desc.hpp, filled by launch_mfx_desc); `queue`: one zeroed device int (the work counter)
 int launch_mfx_desc(const GridView &g, const int32_t *nodes, int32_t count, uint32_t *desc, hipStream_t stream);
-int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int add_neumann, double *out,
+// `cls`: the size class of every node of the list (mfx_desc.hpp: mfx_size_class -- one kernel instantiation per class)
+int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int cls, int add_neumann, double *out,
                    double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_mfx();
 // quad nodes (kernels_gls_quad4.hip: 4 cells, 4 internal + 4 boundary faces -- the nodes inside a boundary face of a hexahedron

@@ -25,6 +25,18 @@ namespace nin {
 constexpr int kMfxMaxFronts = 16, kMfxMaxDense = 21, kMfxMaxFree = 16, kMfxDescWords = 56;
 constexpr int kMfxMaxRows = 160, kMfxMaxCells = kMfxMaxFronts + kMfxMaxDense, kMfxMaxFaces = 63;
 constexpr int kMfxW0 = 1, kMfxW1 = 17, kMfxSlotTable = 33, kMfxFree0 = 39;
+// Size classes of the dense problem (kernels_gls_mfx.hip: one instantiation and one list of the launch plan each): rows <= 16 TQ,
+// pivot columns nc = 3 D < 4 TCB for (TQ, TCB) = (6, 10), (7, 11), (8, 13), (9, 15), (10, 16)
+constexpr int kMfxClasses = 5;
+NIN_HD inline int mfx_size_class(int F, int D, int nfree) {
+    const int rows = 7 * F + D + 3 * nfree, nc = 3 * D;
+    if (rows <= 96 && nc < 40) return 0;
+    if (rows <= 112 && nc < 44) return 1;
+    if (rows <= 128 && nc < 52) return 2;
+    if (rows <= 144 && nc < 60) return 3;
+    if (rows <= 160 && nc < 64) return 4;
+    return -1;
+}
 
 #ifdef __HIPCC__
 struct MfxGraph {
@@ -62,7 +74,7 @@ __device__ inline bool mfx_graph(const GridView &g, int32_t p, MfxGraph &G) {
     return true;
 }
 
-// 0: not for this kernel; 1: the words are filled
+// 0: not for this kernel; 1 + size class: the words are filled
 __device__ inline int mfx_descriptor(const GridView &g, int32_t p, uint32_t w[kMfxDescWords]) {
     MfxGraph G;
     if (!mfx_graph(g, p, G)) return 0;
@@ -110,7 +122,7 @@ __device__ inline int mfx_descriptor(const GridView &g, int32_t p, uint32_t w[kM
         w[kMfxW0 + f] |= ((uint32_t)fi << (6 + 6 * k)) | ((a_front ? 1u : 0u) << (24 + k));
         w[kMfxW1 + f] |= (uint32_t)rank[oc] << (5 * k);
     }
-    return 1;
+    return 1 + mfx_size_class(F, D, nfree);
 }
 #endif
 

@@ -25,6 +25,15 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+class _PlanCounts(dict):
+    """Nodes per kernel of the GLS launch plan; `plan["mfx"]` = the wide multifrontal kernel's five size classes together."""
+
+    def __missing__(self, key):
+        if key == "mfx":
+            return sum(v for k, v in self.items() if k.startswith("mfx_"))
+        raise KeyError(key)
+
+
 class Grid:
     """Grid(dim, n_elems, n_points, npoel, nfael, lnofa, lpofa, nedel, lpoed, connectivity,
     element_types, logging=False, build_edges=False)  -- grid.pyx:47-53.
@@ -180,12 +189,12 @@ class Grid:
         _lib.check(_lib.load().nin_grid_release_scratch(self._h))
 
     PLAN_KERNELS = ("block1", "block2", "block4", "block8", "scratch", "hex8", "mfw_large", "mfw_small", "mfw_general", "small4", "small8",
-                    "small12", "quad4", "mfx")
+                    "small12", "quad4", "mfx_6x10", "mfx_7x11", "mfx_8x13", "mfx_9x15", "mfx_10x16")
 
     def gls_plan_flops(self):
         """Per kernel of the GLS launch plan (nin_gls_plan_flops): {kernel: (algorithmic flops, reference-equivalent dgels flops,
         nodes computed)} for one launch over all nodes; needs the fields on the device (a DevicePlan or an interpolate() first)."""
-        alg, ref, comp = np.zeros(14), np.zeros(14), np.zeros(14, dtype=np.int64)
+        alg, ref, comp = np.zeros(18), np.zeros(18), np.zeros(18, dtype=np.int64)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         _lib.check(_lib.load().nin_gls_plan_flops(self._h, p(alg), p(ref), p(comp)))
         return {k: (float(alg[i]), float(ref[i]), int(comp[i])) for i, k in enumerate(self.PLAN_KERNELS)}
@@ -195,7 +204,6 @@ class Grid:
         node and global scratch, the cube-node kernel, the one-wavefront multifrontal kernel (two-coloured nodes large / small, general kind), the one-wavefront dense
         kernel for small nodes (at most 4 / 8 / 12 cells), the two-lanes-per-node kernel for the nodes inside a boundary
         face of a hexahedron mesh, the wide one-wavefront multifrontal kernel (interior nodes of unstructured meshes)."""
-        counts = np.zeros(14, dtype=np.int64)
+        counts = np.zeros(18, dtype=np.int64)
         _lib.check(_lib.load().nin_gls_plan(self._h, counts.ctypes.data_as(ctypes.c_void_p)))
-        return dict(zip(("block1", "block2", "block4", "block8", "scratch", "hex8", "mfw_large", "mfw_small", "mfw_general", "small4", "small8",
-                         "small12", "quad4", "mfx"), counts.tolist()))
+        return _PlanCounts(zip(self.PLAN_KERNELS, counts.tolist()))

@@ -1,5 +1,7 @@
-// tools/test_xstrip.hip -- the dense phase of kernels_gls_mfx.hip (mfx_strips.hpp: xstrip_factor) alone, against a host
-// Householder QR: random nrows x (nc + 1) problems, every size class.  Build + run on the GPU box:
+// tools/test_xstrip.hip -- the dense phase of kernels_gls_mfx.hip alone, against a host Householder QR: random nrows x (nc + 1)
+// problems through (a) mfw_strips.hpp's unrolled strip_factor<TQ, TCB> in the five size classes the kernel instantiates and
+// (b) mfx_strips.hpp's single-body xstrip_factor (wave-uniform branches; round 4's first form, kept as the A/B baseline: it is
+// 1.9 x slower, see the timing lines).  Build + run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ninpol_amd/csrc tools/test_xstrip.hip -o tools/_bin/test_xstrip && tools/_bin/test_xstrip
 #include <hip/hip_runtime.h>
 
@@ -73,6 +75,27 @@ __global__ __launch_bounds__(64) void k_time_unrolled(const double *A, int lda, 
     Rout[(size_t)blockIdx.x * 64 + lane] = acc + Rm[lane];
 }
 
+template <int TQ, int TCB>
+__global__ __launch_bounds__(64) void k_factor_class(const double *A, int lda, int nc, int nrows, double *Rout, double *rr_out) {
+    __shared__ double Rm[64 * XRP];
+    const int lane = threadIdx.x, si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
+    for (int i = lane; i < 64 * XRP; i += 64) Rm[i] = 0.0;
+    double C[TQ][TCB];
+#pragma unroll
+    for (int q = 0; q < TQ; ++q)
+#pragma unroll
+        for (int cb = 0; cb < TCB; ++cb) {
+            const int row = 16 * q + 4 * sb + si, col = 4 * cb + sj;
+            C[q][cb] = (row < nrows && col <= nc) ? A[row * lda + col] : 0.0;
+        }
+    __syncthreads();
+    nin::mfwstrips::SubStamps ST;
+    const double rr = nin::mfwstrips::strip_factor<TQ, TCB>(C, nc, lane, Rm, XRP, ST);
+    __syncthreads();
+    for (int i = lane; i < 64 * XRP; i += 64) Rout[i] = Rm[i];
+    if (lane == 0) *rr_out = rr;
+}
+
 // host: Householder QR of the nrows x (nc + 1) matrix on its first nc columns; returns R (nc x (nc + 1)) and |(Q^T c)(nc:)|^2
 static void host_qr(std::vector<double> a, int lda, int nrows, int nc, std::vector<double> &R, double &rr) {
     for (int k = 0; k < nc; ++k) {
@@ -113,27 +136,37 @@ int main(int argc, char **argv) {
         for (int r = 0; r < nrows; ++r)
             for (int c = 0; c <= nc; ++c) A[r * lda + c] = (gen() % 4 == 0) ? 0.0 : nd(gen);   // some structural zeros
         hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(k_factor, dim3(1), dim3(64), 0, 0, dA, lda, nc, nrows, dR, drr);
-        std::vector<double> Rg(64 * XRP);
-        double rrg = 0;
-        if (hipMemcpy(Rg.data(), dR, Rg.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { printf("HIP error\n"); return 2; }
-        hipMemcpy(&rrg, drr, 8, hipMemcpyDeviceToHost);
         std::vector<double> R;
         double rr;
         host_qr(A, lda, nrows, nc, R, rr);
-        double err = 0, scale = 0;
-        int wi = -1, wj = -1;
-        for (int k = 0; k < nc; ++k)
-            for (int j = k; j <= nc; ++j) {
-                const double e = std::fabs(Rg[k * XRP + j] - R[k * (nc + 1) + j]);
-                if (!(e <= err)) { err = e; wi = k; wj = j; }
-                scale = std::fmax(scale, std::fabs(R[k * (nc + 1) + j]));
+        for (int form = 0; form < 2; ++form) {
+            const char *what = "single body";
+            if (form == 0) hipLaunchKernelGGL(k_factor, dim3(1), dim3(64), 0, 0, dA, lda, nc, nrows, dR, drr);
+            else {   // the smallest class that holds the problem, as the kernel picks it
+                if (nrows <= 96 && nc < 40) { hipLaunchKernelGGL((k_factor_class<6, 10>), dim3(1), dim3(64), 0, 0, dA, lda, nc, nrows, dR, drr); what = "class 6 x 10"; }
+                else if (nrows <= 112 && nc < 44) { hipLaunchKernelGGL((k_factor_class<7, 11>), dim3(1), dim3(64), 0, 0, dA, lda, nc, nrows, dR, drr); what = "class 7 x 11"; }
+                else if (nrows <= 128 && nc < 52) { hipLaunchKernelGGL((k_factor_class<8, 13>), dim3(1), dim3(64), 0, 0, dA, lda, nc, nrows, dR, drr); what = "class 8 x 13"; }
+                else if (nrows <= 144 && nc < 60) { hipLaunchKernelGGL((k_factor_class<9, 15>), dim3(1), dim3(64), 0, 0, dA, lda, nc, nrows, dR, drr); what = "class 9 x 15"; }
+                else { hipLaunchKernelGGL((k_factor_class<10, 16>), dim3(1), dim3(64), 0, 0, dA, lda, nc, nrows, dR, drr); what = "class 10 x 16"; }
             }
-        const double erel = err / scale, err_rr = std::fabs(rrg - rr) / rr;
-        const bool ok = erel < 1e-12 && err_rr < 1e-11;
-        bad += !ok;
-        printf("%3d x %2d: max |R - R_host| / max|R| = %.2e at (%d, %d)   rr %.6e vs %.6e (%.1e)  %s\n", nrows, nc, erel, wi, wj, rrg, rr, err_rr,
-               ok ? "ok" : "FAIL");
+            std::vector<double> Rg(64 * XRP);
+            double rrg = 0;
+            if (hipMemcpy(Rg.data(), dR, Rg.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { printf("HIP error\n"); return 2; }
+            hipMemcpy(&rrg, drr, 8, hipMemcpyDeviceToHost);
+            double err = 0, scale = 0;
+            int wi = -1, wj = -1;
+            for (int k = 0; k < nc; ++k)
+                for (int j = k; j <= nc; ++j) {
+                    const double e = std::fabs(Rg[k * XRP + j] - R[k * (nc + 1) + j]);
+                    if (!(e <= err)) { err = e; wi = k; wj = j; }
+                    scale = std::fmax(scale, std::fabs(R[k * (nc + 1) + j]));
+                }
+            const double erel = err / scale, err_rr = std::fabs(rrg - rr) / rr;
+            const bool ok = erel < 1e-12 && err_rr < 1e-11;
+            bad += !ok;
+            printf("%3d x %2d %-13s: max |R - R_host| / max|R| = %.2e at (%d, %d)   rr %.6e vs %.6e (%.1e)  %s\n", nrows, nc, what, erel, wi, wj, rrg, rr,
+                   err_rr, ok ? "ok" : "FAIL");
+        }
     }
     // timing: the same 118 x 48 problem on 1 / 256 / 1024 / 2048 wavefronts (blocks of one wave), 20 factorisations each
     if (timing) {
