@@ -37,6 +37,10 @@ using namespace mfwstrips;
 // reads the zeros in front, no select.  A front's 7 fill rows have 3 cells, a free face's 3 rows 2, a dense cell's row 1 (c = 1).
 // Rows: 7 f + i (fill row i of front f), 7 F + d (dense cell d), 7 F + D + 3 q + k (row k of free face q).
 constexpr int XROW = 13;
+#ifndef NIN_MFX_TWO_WAVE_TILES
+#define NIN_MFX_TWO_WAVE_TILES 104     // classes of up to this many tiles run at two wavefronts per SIMD (256 registers: the 7 x 11 class spills 256 B,
+                                       // the 8 x 13 class 528 B a lane -- and still gain 22 % / 12 % from the second wave: A/B in one session)
+#endif
 template <int TQ, int TCB>
 struct XDims {
     static constexpr int RP = 4 * TCB + 1;               // pitch of R in LDS (odd: lane = row reads are conflict-free)
@@ -44,7 +48,7 @@ struct XDims {
     static constexpr int STAGE = 16 * TQ * XROW, RSZ = NP * RP;
     static constexpr int MAIN = ((STAGE > RSZ ? STAGE : RSZ) + 1) & ~1;
     static constexpr int Y = MAIN, W = Y + 64, Z = W + 40, DESC = Z + 2, PER_WAVE = DESC + kMfxDescWords / 2;
-    static constexpr int WAVES = TQ * TCB <= 60 ? 2 : 1;   // wavefronts per SIMD (60 tiles: the registers of half a SIMD lane hold them)
+    static constexpr int WAVES = TQ * TCB <= NIN_MFX_TWO_WAVE_TILES ? 2 : 1;   // wavefronts per SIMD (60 tiles: the registers of half a SIMD lane hold them)
 };
 
 // The dense phase of one node: gather the rows from the staging area into TQ x TCB tiles (16 rows x 4 columns each) and factor
@@ -347,7 +351,8 @@ int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc
     if (cls < 0 || cls >= kMfxClasses) return -1;
     int64_t blocks = count;
     // persistent: one wavefront per workgroup, one (class 0: two) per SIMD -- the register file of a SIMD lane belongs to one (two) node(s)
-    const int64_t cap = 4 * 256 * (cls == 0 ? 2 : 1);
+    constexpr int tiles[kMfxClasses] = {6 * 10, 7 * 11, 8 * 13, 9 * 15, 10 * 16};
+    const int64_t cap = 4 * 256 * (tiles[cls] <= NIN_MFX_TWO_WAVE_TILES ? 2 : 1);
     if (blocks > cap) blocks = cap;
 #define NIN_MFX_LAUNCH(TQ, TCB)                                                                                                      \
     hipLaunchKernelGGL((nin_gls_mfx_kernel<TQ, TCB>), dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, desc, count, add_neumann, out, \
