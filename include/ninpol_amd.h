@@ -209,6 +209,32 @@ int nin_gls_plan(const nin_grid *g, int64_t counts[18]);
  * Needs nin_fields_set (the Neumann flags decide which boundary nodes are computed). */
 int nin_gls_plan_flops(nin_grid *g, double alg[18], double ref[18], int64_t computed[18]);
 
+/* ---- multi-GPU: the all-gather of the path as direct peer-to-peer writes ------------------------------------------
+ * Replaces nothing in the reference (it is single-process); it is the exchange step north_star adds -- "a single allgatherv to
+ * reassemble the COO triplets" -- without a collective library: rank r writes its block straight into slot r of every peer's
+ * gathered buffer, one device-to-device copy per peer, each on its own stream (an MI355X has one xGMI link to each of its seven
+ * peers: seven copies in flight on seven links; a ring all-gather uses one link at a time).  The library does no rendezvous: the
+ * caller exchanges the 64-byte handles by its own means (MPI, torch.distributed, a file) and puts a barrier of its own between
+ * "every rank's pushes are complete" and "read the gathered buffer".  INTEGRATION.md shows the call sequence.
+ *
+ *   nin_exchange_create     a gathered buffer of world slots of slot_bytes (rounded up to 256) on `device`
+ *   nin_exchange_handle     this rank's 64-byte IPC handle (hipIpcMemHandle_t) -> handle64
+ *   nin_exchange_connect    all_handles: world x 64 bytes, rank-major; opens the peers' buffers (once)
+ *   nin_exchange_push       bytes from dev_src (device memory of this rank) -> offset `offset` of slot `rank` in EVERY rank's buffer,
+ *                           this rank's own included; asynchronous, ordered behind everything enqueued on `stream` so far
+ *   nin_exchange_wait_sent  host_wait = 0: `stream` waits for this rank's pushes; 1: the host does
+ *   nin_exchange_buffer     this rank's gathered buffer (device pointer): slot r at r * nin_exchange_slot_bytes() */
+#define NIN_EXCHANGE_HANDLE_BYTES 64
+typedef struct nin_exchange nin_exchange;
+int nin_exchange_create(int device, int rank, int world, size_t slot_bytes, nin_exchange **out);
+void nin_exchange_destroy(nin_exchange *x);
+int nin_exchange_handle(nin_exchange *x, void *handle64);
+int nin_exchange_connect(nin_exchange *x, const void *all_handles);
+int nin_exchange_push(nin_exchange *x, const void *dev_src, size_t bytes, size_t offset, void *stream);
+int nin_exchange_wait_sent(nin_exchange *x, void *stream, int host_wait);
+void *nin_exchange_buffer(nin_exchange *x);
+size_t nin_exchange_slot_bytes(const nin_exchange *x);
+
 #ifdef __cplusplus
 }
 #endif

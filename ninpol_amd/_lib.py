@@ -21,6 +21,8 @@ EXPORTS = (
     "nin_apply_device", "nin_apply_fields_host", "nin_pack_connectivity", "nin_pack_table_row", "nin_diff_mag",
     "nin_algorithmic_bytes", "nin_kernel_name", "nin_gls_plan", "nin_gls_plan_flops", "nin_host_alloc", "nin_host_free", "nin_hash64",
     "nin_grid_release_scratch",
+    "nin_exchange_create", "nin_exchange_destroy", "nin_exchange_handle", "nin_exchange_connect", "nin_exchange_push",
+    "nin_exchange_wait_sent", "nin_exchange_buffer", "nin_exchange_slot_bytes",
 )
 
 _lib = None
@@ -76,6 +78,17 @@ def load():
     L.nin_host_free.argtypes = [vp]
     L.nin_hash64.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
     L.nin_grid_release_scratch.argtypes = [vp]
+    L.nin_exchange_create.argtypes = [i32, i32, i32, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.nin_exchange_destroy.argtypes = [vp]
+    L.nin_exchange_destroy.restype = None
+    L.nin_exchange_handle.argtypes = [vp, vp]
+    L.nin_exchange_connect.argtypes = [vp, vp]
+    L.nin_exchange_push.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t, vp]
+    L.nin_exchange_wait_sent.argtypes = [vp, vp, i32]
+    L.nin_exchange_buffer.argtypes = [vp]
+    L.nin_exchange_buffer.restype = vp
+    L.nin_exchange_slot_bytes.argtypes = [vp]
+    L.nin_exchange_slot_bytes.restype = ctypes.c_size_t
     _lib = L
     return L
 

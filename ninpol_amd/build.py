@@ -36,6 +36,8 @@ UNITS = [
     # device-side grid build: no contraction, like grid_host.cpp (float32 normals must match the reference)
     ("grid_device.hip", "hipcc", ["-ffp-contract=off"]),
     ("abi.hip", "hipcc", ["-Wno-unknown-pragmas"]),
+    # the peer-to-peer exchange of the multi-GPU path (nin_exchange_*): HIP runtime calls only, no kernel
+    ("exchange.hip", "hipcc", []),
 ]
 
 

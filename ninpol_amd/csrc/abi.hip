@@ -43,6 +43,23 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+namespace nin {
+// the same for the other translation units of the C ABI (exchange.hip): sets what nin_last_error() returns
+int abi_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace nin
+
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \

@@ -85,6 +85,76 @@ def allgatherv(tensors, counts_hint=None, group=None):
     return out
 
 
+class P2PExchange:
+    """The all-gather as direct peer-to-peer writes (libninpol_amd's nin_exchange_*, csrc/exchange.hip): every rank owns a gathered
+    buffer of `world` slots; a push copies this rank's block straight into slot `rank` of every peer's buffer, one copy per peer on
+    its own stream -- seven xGMI links in use at once where a ring all-gather uses one -- and nothing but the block itself travels (no
+    padding to the longest shard).  The process group is used for the 64-byte handle exchange (once) and for the barrier between
+    "all pushes complete" and "read": control only, no payload."""
+
+    def __init__(self, device, rank, world, slot_bytes, group=None):
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        self._lib, self._L = _lib, _lib.load()
+        self.rank, self.world, self.group, self.device = rank, world, group, device
+        h = ctypes.c_void_p()
+        _lib.check(self._L.nin_exchange_create(int(device), int(rank), int(world), int(slot_bytes), ctypes.byref(h)))
+        self._h = h
+        mine = ctypes.create_string_buffer(64)
+        _lib.check(self._L.nin_exchange_handle(self._h, mine))
+        handles = [None] * world
+        dist.all_gather_object(handles, mine.raw, group=group)
+        allh = ctypes.create_string_buffer(b"".join(handles), 64 * world)
+        _lib.check(self._L.nin_exchange_connect(self._h, allh))
+        self.slot_bytes = int(self._L.nin_exchange_slot_bytes(self._h))
+        self._ptr = int(self._L.nin_exchange_buffer(self._h))
+        self._torch = torch
+
+    def push(self, tensor, offset_bytes=0, stream=None):
+        """tensor: this rank's block (contiguous, on this rank's device) -> slot `rank` of every rank's buffer."""
+        import ctypes
+        t = self._torch
+        st = t.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        self._lib.check(self._L.nin_exchange_push(self._h, ctypes.c_void_p(tensor.data_ptr()), tensor.numel() * tensor.element_size(),
+                                                  int(offset_bytes), ctypes.c_void_p(st)))
+
+    def complete(self):
+        """Every rank's pushes have landed in every rank's buffer when this returns (collective)."""
+        import torch.distributed as dist
+        self._lib.check(self._L.nin_exchange_wait_sent(self._h, None, 1))
+        dist.barrier(group=self.group)
+
+    def slot(self, r, dtype, count, offset_bytes=0):
+        """Rank r's block in THIS rank's gathered buffer as a tensor view (no copy)."""
+        t = self._torch
+        es = t.empty(0, dtype=dtype).element_size()
+        return _device_view(t, self._ptr + r * self.slot_bytes + offset_bytes, count, dtype, self.device, es)
+
+    def close(self):
+        if self._h:
+            self._L.nin_exchange_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _device_view(torch, ptr, count, dtype, device, elem_size):
+    """A torch tensor over `count` elements of device memory the library owns (via __cuda_array_interface__)."""
+    typestr = {torch.float64: "<f8", torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+
+    class _Mem:
+        __cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    if count == 0:
+        return torch.empty(0, dtype=dtype, device=torch.device("cuda", device))
+    return torch.as_tensor(_Mem(), device=torch.device("cuda", device))
+
+
 class ShardedPlan:
     """Device-resident `interpolate(variable, method)` / `apply(...)` over the process group.
 
@@ -142,6 +212,10 @@ class ShardedPlan:
         self.pending = [None, None]
         self.n_steps = 0
         self._apply = {}                      # n_fields -> buffers of apply_step
+        # the matrix exchange as direct peer-to-peer writes (nin_exchange_*) instead of the all-gather: NIN_EXCHANGE=p2p, or
+        # ShardedInterpolator(exchange="p2p").  The RCCL all-gather stays the default until a scaling curve exists.
+        self.p2p = None
+        self.exchange_mode = getattr(S, "exchange_mode", "allgather")
 
     # -- what depends on the caller's tables -------------------------------------------------------------------------
     def _derive_gather_neumann(self):
@@ -218,10 +292,27 @@ class ShardedPlan:
             self.exchange(b)
         return b
 
+    def _p2p_setup(self):
+        S = self.S
+        slot = 8 * (self.mx_nnz + self.mx_rows)       # values, then the Neumann rows
+        self.p2p = [P2PExchange(S.device, S.rank, S.world, slot, S.group) for _ in range(2)]   # one per buffer set
+        self.vals = [None, None]
+        self.neumann_p2p = [None, None]
+
     def exchange(self, b):
         """The all-gather of buffer set b alone (asynchronous; bench.py times it without the kernel too)."""
         S = self.S
         lo = S.own_lo
+        if self.exchange_mode == "p2p":
+            # each rank writes its UNPADDED value block (and Neumann rows) straight into every peer's gathered buffer
+            if self.p2p is None:
+                self._p2p_setup()
+            x = self.p2p[b]
+            x.push(self.out[b][self.eb:self.ee])
+            if self.gather_neumann:
+                x.push(self.nws[b][lo:lo + self.n_owned], offset_bytes=8 * self.mx_nnz)
+            self.pending[b] = [_P2PWait(self, b)]
+            return
         self.pending[b] = [S._gather(self.vals[b], self.out[b][self.eb:self.eb + self.mx_nnz], async_op=True)]
         if self.gather_neumann:
             self.pending[b].append(S._gather(self.neumann[b], self.nws[b][lo:lo + self.mx_rows], async_op=True))
@@ -229,6 +320,8 @@ class ShardedPlan:
 
     def pieces(self, t, which):
         """Per-rank pieces of a gathered tensor (which: 0 = per entry, 1 = per row)."""
+        if isinstance(t, _P2PGathered):
+            return t.pieces
         mx = self.mx_nnz if which == 0 else self.mx_rows
         return [t[r * mx:r * mx + int(self.lens[r, which])] for r in range(self.S.world)]
 
@@ -278,6 +371,31 @@ class ShardedPlan:
         return torch.cat([recv[r, :, :int(rows[r])] for r in range(self.S.world)], dim=1)
 
 
+class _P2PGathered:
+    """What `vals[b]` / `neumann[b]` are in p2p mode: the per-rank views into this rank's gathered buffer."""
+
+    def __init__(self, pieces):
+        self.pieces = pieces
+
+
+class _P2PWait:
+    """The handle ShardedPlan.drain() waits on in p2p mode: completes the pushes of buffer set b (a collective) and publishes
+    the gathered views."""
+
+    def __init__(self, plan, b):
+        self.plan, self.b = plan, b
+
+    def wait(self):
+        import torch
+        p, b = self.plan, self.b
+        x = p.p2p[b]
+        x.complete()
+        W = p.S.world
+        p.vals[b] = _P2PGathered([x.slot(r, torch.float64, int(p.lens[r, 0])) for r in range(W)])
+        if p.gather_neumann:
+            p.neumann[b] = _P2PGathered([x.slot(r, torch.float64, int(p.lens[r, 1]), offset_bytes=8 * p.mx_nnz) for r in range(W)])
+
+
 class ShardedInterpolator:
     """`interpolate()` / `apply()` over a process group: rank r holds the node block [P r / W, P (r+1) / W) of the mesh
     plus the cells around it and computes those rows on its own GPU.  `interpolate()` delivers the whole
@@ -292,13 +410,21 @@ class ShardedInterpolator:
     The CPU tests inject an oracle-backed object here; the product path never does."""
 
     def __init__(self, group=None, device=None, make_interpolator=None, comm_on_host=False, grid_build="host",
-                 num_threads=0):
+                 num_threads=0, exchange=None):
         """device: this rank's GPU (None: the injected compute object works on host tensors -- CPU tests only).
         comm_on_host: stage the all-gather through host tensors (a gloo group next to GPU compute, e.g. several
         ranks rehearsing on one GPU); default: the collective runs on the compute device (backend nccl = RCCL)."""
         import torch
         import torch.distributed as dist
         self.comm_on_host = bool(comm_on_host)
+        # how the matrix travels: "allgather" (one padded all-gather over the process group: RCCL on the GPU box) or "p2p"
+        # (libninpol_amd's nin_exchange_*: direct writes into the peers' buffers; needs a real device)
+        import os as _os
+        self.exchange_mode = exchange or _os.environ.get("NIN_EXCHANGE", "allgather")
+        if self.exchange_mode not in ("allgather", "p2p"):
+            raise ValueError("exchange must be 'allgather' or 'p2p'")
+        if self.exchange_mode == "p2p" and device is None:
+            raise ValueError("exchange='p2p' writes device memory: it needs a GPU (device=...)")
         self.grid_build = grid_build
         self.num_threads = num_threads
         self.group = group

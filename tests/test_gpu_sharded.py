@@ -36,7 +36,7 @@ def _make_mesh(kind):
     return m
 
 
-def _worker(rank, world, port, kind, out_dir):
+def _worker(rank, world, port, kind, out_dir, exchange="allgather"):
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -45,7 +45,7 @@ def _worker(rank, world, port, kind, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        S = ShardedInterpolator(device=0, comm_on_host=True, grid_build=("host", "device")[rank % 2])
+        S = ShardedInterpolator(device=0, comm_on_host=True, grid_build=("host", "device")[rank % 2], exchange=exchange)
         if kind == "slab":
             from ninpol_amd.partition import node_block
             plane_lo, plane_hi = node_block(SLAB[2] + 1, rank, world)
@@ -65,11 +65,14 @@ def _worker(rank, world, port, kind, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["hex", "mixed", "slab"])
-def test_two_ranks_on_one_gpu_match_single_process(kind, tmp_path):
+@pytest.mark.parametrize("kind,exchange", [("hex", "allgather"), ("mixed", "allgather"), ("slab", "allgather"),
+                                           # the matrix exchange as direct peer-to-peer writes through the C ABI (nin_exchange_*): each
+                                           # rank's unpadded block straight into the other's gathered buffer, opened over HIP IPC
+                                           ("mixed", "p2p"), ("slab", "p2p")])
+def test_two_ranks_on_one_gpu_match_single_process(kind, exchange, tmp_path):
     import ninpol_amd
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), exchange), nprocs=world, join=True)
     I = ninpol_amd.Interpolator()
     I.load_mesh(mesh_obj=_make_mesh(kind))
     for meth in ("idw", "ls", "gls"):

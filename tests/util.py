@@ -136,7 +136,7 @@ def elementwise_err(a, b, floor=ELEMENTWISE_FLOOR):
     sel = fin & (bb >= floor * scale) & (bb > 0)
     if not sel.any():
         return 0.0
-    return float((np.abs(a - b)[sel] / bb[sel]).max())
+    return float((np.abs(a[sel] - b[sel]) / bb[sel]).max())
 
 
 def csr_elementwise_err(W, indptr, indices, data, floor=ELEMENTWISE_FLOOR):
@@ -152,7 +152,7 @@ def csr_elementwise_err(W, indptr, indices, data, floor=ELEMENTWISE_FLOOR):
     sel = fin & (bb >= floor * scale[rows]) & (bb > 0)
     if not sel.any():
         return 0.0
-    return float((np.abs(a - b)[sel] / bb[sel]).max())
+    return float((np.abs(a[sel] - b[sel]) / bb[sel]).max())
 
 
 def csr_rowscaled_err(W, indptr, indices, data):
