@@ -376,6 +376,21 @@ def main():
         # (3) the sharded apply: W_block . u on the device + the all-gather of node values (ShardedPlan.apply_step)
         decomposition["compute_only_ms"] = timed_leg(lambda i: splan.step(exchange=False), lambda: None)
         decomposition["exchange_ms"] = timed_leg(lambda i: (splan.drain(i % 2), splan.exchange(i % 2)), splan.drain_all)
+        # (2b) the same exchange as direct peer-to-peer writes through the C ABI (nin_exchange_*: every rank's UNPADDED block straight into
+        # the peers' gathered buffers, one copy stream per peer -- seven xGMI links at once).  Measured beside the all-gather, never
+        # `value`'s path; a failure here must not cost the line
+        try:
+            from ninpol_amd.partition import P2PExchange
+            px = P2PExchange(local_rank, rank, world, 8 * max(splan.mx_nnz, 1))
+            blk = lambda i: splan.out[i % 2][splan.eb:splan.ee]
+            px.push(blk(0))
+            px.complete()
+            ok = bool(torch.equal(px.slot(rank, torch.float64, splan.ee - splan.eb), blk(0)))
+            decomposition["exchange_p2p_ms"] = timed_leg(lambda i: px.push(blk(i)), px.complete)
+            decomposition["exchange_p2p_own_slot_ok"] = ok
+            px.close()
+        except Exception as e:   # noqa: BLE001
+            decomposition["exchange_p2p_error"] = f"{type(e).__name__}: {e}"[:300]
         u_loc = torch.from_numpy(np.ascontiguousarray(
             np.asarray(I.cells_data[I.variable_to_index["cells"]["u"]])[:g.n_elems].reshape(1, -1))).to(dev)
         splan.apply_step(u_loc)
@@ -472,6 +487,12 @@ def main():
         if "compute_only_ms" in decomposition:
             line["compute_only_Mnodes_s"] = round(total_nodes / decomposition["compute_only_ms"] / 1e3, 3)
             line["exchange_ms"] = round(decomposition["exchange_ms"], 4)
+            if "exchange_p2p_ms" in decomposition:
+                line["exchange_p2p_ms"] = round(decomposition["exchange_p2p_ms"], 4)
+                line["exchange_p2p_note"] = ("the same value blocks as direct peer-to-peer writes (nin_exchange_*, no padding, one copy stream per "
+                                             f"peer), timed alone; own slot verified: {decomposition['exchange_p2p_own_slot_ok']}")
+            if "exchange_p2p_error" in decomposition:
+                line["exchange_p2p_error"] = decomposition["exchange_p2p_error"]
             line["exchange_note"] = ("all-gather of one step's CSR values (8 B per entry" +
                                      (" + 8 B per row of neumann_ws" if splan.gather_neumann else "") +
                                      f"), timed alone: {splan.mx_nnz * 8 * (world - 1) / 1e9:.3f} GB received per GPU")
