@@ -4,7 +4,7 @@
 # Pass 1: --kernel-trace --stats of the default bench (no CPU-baseline leg).  Passes 2-4: separate --pmc runs
 # (FETCH_SIZE; WRITE_SIZE; SQ counters), never combined with other trace domains.
 set -u
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
@@ -17,10 +17,12 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
   timeout -k 10 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-other-meshes --no-e2e > $OUT/pmc$i.json 2> $OUT/pmc$i.err || { echo "pmc pass $i failed"; tail -5 $OUT/pmc$i.err; exit 1; }
 done
 # the block kernel by size class on the mixed and Kuhn-tet meshes (BASELINE config [3] at size: mixed10m)
-NIN_GRID_BUILD=device timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mixed_tet -- python3 tools/time_methods.py mixed tet40 wedge60 mixed10m > $OUT/methods_by_mesh.txt 2> $OUT/mixed_tet.err || { echo "mixed/tet pass failed"; tail -5 $OUT/mixed_tet.err; }
+NIN_GRID_BUILD=device timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mixed_tet -- python3 tools/time_methods.py mixed tet40 wedge60 mixed10m del54 > $OUT/methods_by_mesh.txt 2> $OUT/mixed_tet.err || { echo "mixed/tet pass failed"; tail -5 $OUT/mixed_tet.err; }
 # issue-side counters of the one-wavefront multifrontal kernel on the Kuhn-tet mesh: the strip form and the row-lane form
 bash tools/pmc_tet.sh $OUT/pmc_tet_strips > $OUT/pmc_tet_strips.txt 2>&1 || echo "tet pmc (strips) failed"
 NIN_MFW_NO_STRIPS=1 bash tools/pmc_tet.sh $OUT/pmc_tet_rows > $OUT/pmc_tet_rows.txt 2>&1 || echo "tet pmc (rows) failed"
+# ... and of the wide multifrontal kernel (all its size classes together) on a Delaunay mesh
+bash tools/pmc_tet.sh $OUT/pmc_del_mfx del40 nin_gls_mfx > $OUT/pmc_del_mfx.txt 2>&1 || echo "delaunay pmc failed"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, json, collections, os
 out = sys.argv[1]
@@ -40,7 +42,7 @@ if mt:
     with open(out + "/kernel_stats_mixed_tet.csv", "w", newline="") as f:
         csv.writer(f, quoting=csv.QUOTE_ALL).writerows([r for r in csv.reader(open(mt[0]))])
 acc = collections.defaultdict(list)
-for f in glob.glob(out + "/pmc[0-9]/**/*counter_collection.csv", recursive=True) + glob.glob(out + "/pmc_tet_*/p[0-9]/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(out + "/pmc[0-9]/**/*counter_collection.csv", recursive=True) + glob.glob(out + "/pmc_tet_*/p[0-9]/**/*counter_collection.csv", recursive=True) + glob.glob(out + "/pmc_del_*/p[0-9]/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         if k.startswith("nin_"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))   # (the apply form of the cube kernel, nin_gls_hex8w2_kernel<true>, is its own row)
