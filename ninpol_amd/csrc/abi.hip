@@ -1151,8 +1151,7 @@ int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t
     }
     // GLS on a mesh with cube nodes: the cube-node kernel forms W . u itself (the 64 bytes of a node's row are neither written
     // nor read again); the other kernels write their rows as always and a list kernel applies those (NIN_APPLY_NO_FUSION: off)
-    if (method == NIN_METHOD_GLS && d.hex8.count > 0 && d.noncube_nodes_ready && getenv("NIN_APPLY_NO_FUSION") == nullptr &&
-        getenv("NIN_HEX8_ONE_WAVE") == nullptr) {
+    if (method == NIN_METHOD_GLS && d.hex8.count > 0 && d.noncube_nodes_ready && getenv("NIN_APPLY_NO_FUSION") == nullptr) {
         if (!d.fields_set) return fail(NIN_ESTATE, "nin_fields_set has not been called");
         if (!d.have_perm) return fail(NIN_ESTATE, "GLS needs permeability and diff_mag");
         if (d.gls_too_large) return fail(NIN_ERANGE, "a node's GLS system has more than 1024 rows: beyond the fallback kernel");

@@ -57,165 +57,6 @@ __device__ __forceinline__ double quad_bcast(double v) { return dpp_mov<L * 0x55
 constexpr int NPW = 16;          // nodes per wavefront pass (4 lanes each)
 constexpr int NR = 8, NC = 13;   // phase 2, per lane: 8 rows x (12 odd columns + c)
 
-// Loads whose results are not looked at before a later point of the pass, written so that they STAY where they are
-// put: the destination is an accumulation register named in the instruction itself (a value the register allocator
-// parks in an AGPR on its own gets there through a VGPR copy -- i.e. a full wait right behind the load -- and plain
-// loads get sunk to their first use, a pass later).  The compiler does not know these are in flight: every consumer
-// goes through settle(), an s_waitcnt vmcnt(0) that takes the values in and hands them out again.  Its own waits stay
-// correct with unknown loads in flight, only more conservative (vmcnt counts in order); the one place it waits, for
-// the geometry at the top of a pass, comes before any of these is issued.
-__device__ __forceinline__ uint32_t lazy_u32(const void *ptr) {
-    uint32_t v;
-    asm volatile("global_load_dword %0, %1, off" : "=a"(v) : "v"(ptr) : "memory");
-    return v;
-}
-// the same, held behind the computation of `after` by a data dependence (pure arithmetic may otherwise sink below it)
-__device__ __forceinline__ uint32_t lazy_u32_after(const void *ptr, double after) {
-    uint32_t v;
-    asm volatile("global_load_dword %0, %1, off" : "=a"(v) : "v"(ptr), "v"(after) : "memory");
-    return v;
-}
-__device__ __forceinline__ uint32_t lazy_u8(const void *ptr) {
-    uint32_t v;
-    asm volatile("global_load_ubyte %0, %1, off" : "=a"(v) : "v"(ptr) : "memory");
-    return v;
-}
-__device__ __forceinline__ double lazy_f64(const void *ptr) {
-    double v;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(v) : "v"(ptr) : "memory");
-    return v;
-}
-// returning atomic add of 1 (one lane): the work-queue ticket
-__device__ __forceinline__ uint32_t lazy_ticket(int32_t *ptr) {
-    uint32_t v, one = 1;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=a"(v) : "v"(ptr), "a"(one) : "memory");
-    return v;
-}
-__device__ __forceinline__ void settle(uint32_t &a, uint32_t &b, uint32_t &c) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+a"(a), "+a"(b), "+a"(c) : : "memory");
-}
-__device__ __forceinline__ void settle(uint32_t &a, uint32_t &b, uint32_t &c, double &x, double &y, double &z) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+a"(a), "+a"(b), "+a"(c), "+a"(x), "+a"(y), "+a"(z) : : "memory");
-}
-__device__ __forceinline__ void settle(uint32_t (&a)[8]) {
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]), "+a"(a[6]), "+a"(a[7])
-                 :
-                 : "memory");
-}
-
-// Everything a lane reads from HBM for its node, in the order of the dependent chain
-// (work ticket, list entry -> CSR row starts -> cell / face ids -> geometry and permeability).
-struct Fetch {
-    uint32_t p, dsc, eb, fb, flag;   // (ids unsigned: widening them for the address arithmetic is free)
-    uint32_t ticket;                 // the work-queue value read alongside level 0 (lane 0 only)
-    bool valid;
-    uint32_t id[8];                  // ce, co, cn[0..2], f[0..2]
-    double xv[3], cen_e[3], cen_o[3], Ke[9], dme, fcen[3][3], fn[3][3], Kn[3][9], dmn[3];
-
-    __device__ __forceinline__ void level0(const int32_t *nodes, const int32_t *desc, int32_t idx, int32_t count, int l,
-                                           int32_t *queue, bool leader, double after) {
-        valid = idx < count;
-        const uint32_t sel = (uint32_t)(valid ? idx : count - 1);   // past the end: a clamped (valid) entry, never stored
-        p = lazy_u32_after(nodes + sel, after);
-        dsc = lazy_u32(desc + 4 * (size_t)sel + l);
-        ticket = 0;
-        if (leader) ticket = lazy_ticket(queue);
-    }
-    __device__ __forceinline__ void level1(const GridView &g) {
-        settle(p, dsc, ticket);
-        eb = lazy_u32(g.esup_ptr + p);
-        fb = lazy_u32(g.fsup_ptr + p);
-        flag = lazy_u8(g.flags + p);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) xv[k] = lazy_f64(g.coords + 3 * (size_t)p + k);
-    }
-    __device__ __forceinline__ void level2(const GridView &g) {
-        settle(eb, fb, flag, xv[0], xv[1], xv[2]);
-        id[0] = lazy_u32(g.esup + eb + (dsc & 7));
-        id[1] = lazy_u32(g.esup + eb + ((dsc >> 3) & 7));
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const uint32_t w = dsc >> (6 + 8 * i);
-            id[2 + i] = lazy_u32(g.esup + eb + ((w >> 4) & 7));
-            id[5 + i] = lazy_u32(g.fsup + fb + (w & 15));
-        }
-    }
-    __device__ __forceinline__ void level3(const GridView &g) {
-        settle(id);
-        const uint32_t ce = id[0], co = id[1];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            cen_e[k] = g.centroids[3 * (size_t)ce + k];
-            cen_o[k] = g.centroids[3 * (size_t)co + k];
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Ke[k] = g.perm[9 * (size_t)ce + k];
-        dme = g.diff_mag[ce];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const uint32_t cn = id[2 + i], f = id[5 + i];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                fcen[i][k] = g.face_center[3 * (size_t)f + k];
-                fn[i][k] = (double)g.face_normal[3 * (size_t)f + k];
-            }
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Kn[i][k] = g.perm[9 * (size_t)cn + k];
-            dmn[i] = g.diff_mag[cn];
-        }
-    }
-};
-
-// Phase 2, step K: pivot = local row Q = K / 4 of lane LAM = K % 4.  Local rows < Q are retired in every lane, row
-// Q is retired in the lanes below LAM, active (as a plain row) in the lanes above it.
-template <int K>
-__device__ __forceinline__ void p2_step(double (&C)[NR][NC], double (&rinvq)[3], int l) {
-    constexpr int Q = K / 4, LAM = K % 4;
-    const bool is_piv = (l == LAM);
-    const double mx = (l > LAM) ? 1.0 : 0.0;          // row Q counts as part of x only above the pivot lane
-    const double xq = mx * C[Q][K];
-    // |x|^2 without the pivot entry, and the pivot entry alpha itself
-    double ss = xq * xq;
-#pragma unroll
-    for (int r = Q + 1; r < NR; ++r) ss = fma(C[r][K], C[r][K], ss);
-    // partial dots of x with the live columns: independent of the scalars below, they fill that chain's latency
-    double d[NC];
-#pragma unroll
-    for (int j = K + 1; j < NC; ++j) {
-        double a = xq * C[Q][j];
-#pragma unroll
-        for (int r = Q + 1; r < NR; ++r) a = fma(C[r][K], C[r][j], a);
-        d[j] = a;
-    }
-    ss = quad_sum(ss);
-    const double alpha = quad_bcast<LAM>(C[Q][K]);
-    const House h = house_unguarded(alpha, ss);
-    rinvq[Q] = is_piv ? h.rinv : rinvq[Q];
-    const double vpl = is_piv ? h.vp : 0.0;           // the pivot entry of v, in the pivot lane only
-    const double vq = is_piv ? h.vp : xq;             // row Q's entry of v in this lane
-#pragma unroll
-    for (int j = K + 1; j < NC; ++j) {
-        const double e = quad_sum(fma(vpl, C[Q][j], d[j]));
-        const double w = -(h.g * e);
-        C[Q][j] = fma(w, vq, C[Q][j]);                // the pivot lane's row Q becomes row K of R
-#pragma unroll
-        for (int r = Q + 1; r < NR; ++r) C[r][j] = fma(w, C[r][K], C[r][j]);
-    }
-}
-
-template <int K, int KEND>
-struct P2Loop {
-    static __device__ __forceinline__ void run(double (&C)[NR][NC], double (&rinvq)[3], int l) {
-        p2_step<K>(C, rinvq, l);
-        P2Loop<K + 1, KEND>::run(C, rinvq, l);
-    }
-};
-template <int KEND>
-struct P2Loop<KEND, KEND> {
-    static __device__ __forceinline__ void run(double (&)[NR][NC], double (&)[3], int) {}
-};
-
 // Back-substitution of the odd unknowns by columns: row K of R lives in lane K % 4, local row K / 4 (entries
 // C[Q][j], j > K, right-hand side t[Q]).  y_K is formed in its lane and broadcast; every lane then takes
 // R(K', K) y_K off the right-hand sides of its own rows K' < K.
@@ -237,247 +78,9 @@ struct BackLoop<-1> {
     static __device__ __forceinline__ void run(const double (&)[NR][NC], const double (&)[3], double (&)[3], double (&)[12], int) {}
 };
 
-__global__ __launch_bounds__(256, 1) void nin_gls_hex8mf_kernel(GridView g, const int32_t *__restrict__ nodes,
-                                                                const int32_t *__restrict__ desc, int32_t count,
-                                                                int add_neumann, double *__restrict__ out,
-                                                                double *__restrict__ nws, int32_t *__restrict__ queue) {
-    __shared__ double wbuf_all[4][NPW * 8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l = lane & 3, nd = lane >> 2;
-    double *wbuf = wbuf_all[wave];
-
-    const int32_t n_groups = (count + NPW - 1) / NPW;
-    // XCD x walks the x-th contiguous eighth of the node list; its waves pull consecutive 16-node groups off a
-    // per-XCD counter (neighbouring mesh rows meet in one L2 a few passes apart, late CUs take fewer groups)
-    int32_t wg_lo, wg_end;
-    int32_t *q;
-    if ((gridDim.x & 7) == 0) {
-        const int32_t xcd = blockIdx.x & 7, per = (n_groups + 7) / 8;
-        wg_lo = xcd * per;
-        wg_end = (xcd + 1) * per < n_groups ? (xcd + 1) * per : n_groups;
-        q = queue + 16 * xcd;   // one counter per 64-byte line
-    } else {
-        wg_lo = 0;
-        wg_end = n_groups;
-        q = queue;
-    }
-    // lane-role masks (as multipliers): face i of lane l sits on odd slot i (i < 3 - l) or i + 1
-    const double mA0 = (l != 3) ? 1.0 : 0.0, mA1 = (l < 2) ? 1.0 : 0.0, mA2 = (l == 0) ? 1.0 : 0.0;
-    const double mB1 = (l == 3) ? 1.0 : 0.0, mB2 = (l >= 2) ? 1.0 : 0.0, mB3 = (l != 0) ? 1.0 : 0.0;
-
-    // The reads of a pass form a dependent chain (work ticket, list entry -> CSR row starts -> ids -> geometry and
-    // permeability): each level of the NEXT pass is issued at a different point of this one and has long landed when
-    // the following level needs it.  The ticket drawn with level 0 of pass n + 1 names the group of pass n + 2.
-    const bool leader = lane == 0;
-    Fetch cur, nx;
-    int32_t wg, wg_next;
-    {
-        uint32_t t0 = 0, t1 = 0, t2 = 0;
-        if (leader) t0 = lazy_ticket(q);
-        settle(t0, t1, t2);
-        wg = wg_lo + (int32_t)__builtin_amdgcn_readfirstlane(t0);
-        cur.level0(nodes, desc, wg * NPW + nd, count, l, q, leader, 0.0);
-        cur.level1(g);
-        wg_next = wg_lo + (int32_t)__builtin_amdgcn_readfirstlane(cur.ticket);
-        cur.level2(g);
-        cur.level3(g);
-    }
-#ifdef NIN_MF_STAMPS
-#ifndef NIN_MF_STAMP_PASS
-#define NIN_MF_STAMP_PASS 8
-#endif
-    unsigned long long stamps[8];
-    int n_stamp = 0, pass_no = 0;
-#define NIN_MF_STAMP() do { if (n_stamp < 8) { __builtin_amdgcn_sched_barrier(0); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define NIN_MF_STAMP() do { } while (0)
-#endif
-    while (wg < wg_end) {
-#ifdef NIN_MF_STAMPS
-        n_stamp = 0;
-#endif
-        NIN_MF_STAMP();                                   // 0: top of the pass
-        const bool valid = cur.valid;
-        const uint32_t p = cur.p, eb = cur.eb;
-        const uint32_t dsc = cur.dsc;
-        const bool is_neu = (cur.flag & 2) != 0;
-
-        // ---- the front of E_l: rows 0 = cell row, 1 + 3 i + r = row r of face i; own columns in P ------------
-        // nb0[i] = first row of the neighbour-side block of face i; its rows 1, 2 are minus the own block's (sav)
-        double P[10][3], de[3], dod[3], nb0[3][3], sav[3][2][3];
-        {
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                de[t] = cur.cen_e[t] - cur.xv[t];      // gls.pyx:269-277
-                dod[t] = cur.cen_o[t] - cur.xv[t];
-                P[0][t] = de[t];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                // B = [K N; T1; tau T2] (gls.pyx:293-321), row = [-B_a | +B_b] (gls.pyx:340-356)
-                const double N0 = cur.fn[i][0], N1 = cur.fn[i][1], N2 = cur.fn[i][2];
-                const double T0 = cur.xv[0] - cur.fcen[i][0], T1 = cur.xv[1] - cur.fcen[i][1], T2 = cur.xv[2] - cur.fcen[i][2];
-                const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
-                double eta = 0.0;
-                eta = cur.dme > eta ? cur.dme : eta;
-                eta = cur.dmn[i] > eta ? cur.dmn[i] : eta;
-                const double un = sqrt(U0 * U0 + U1 * U1 + U2 * U2);
-                const double tj = face_tau(un, eta);
-                const bool side_a = ((dsc >> (6 + 8 * i + 7)) & 1) != 0;
-                const double sg = side_a ? -1.0 : 1.0;
-                const double *Ke = cur.Ke, *Kn = cur.Kn[i];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    P[1 + 3 * i][t] = sg * (Ke[t * 3 + 0] * N0 + Ke[t * 3 + 1] * N1 + Ke[t * 3 + 2] * N2);
-                    nb0[i][t] = -sg * (Kn[t * 3 + 0] * N0 + Kn[t * 3 + 1] * N1 + Kn[t * 3 + 2] * N2);
-                }
-                sav[i][0][0] = sg * T0; sav[i][0][1] = sg * T1; sav[i][0][2] = sg * T2;
-                sav[i][1][0] = sg * (tj * U0); sav[i][1][1] = sg * (tj * U1); sav[i][1][2] = sg * (tj * U2);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) { P[2 + 3 * i][t] = sav[i][0][t]; P[3 + 3 * i][t] = sav[i][1][t]; }
-            }
-        }
-        NIN_MF_STAMP();                                   // 1: face rows done
-        // next pass: list entry, and the ticket of the pass after it.  Tied to the face rows above: the geometry this
-        // pass has just consumed must have been waited for BEFORE these go out, or that wait covers them too
-        nx.level0(nodes, desc, wg_next * NPW + nd, count, l, q, leader, (P[3][2] + P[6][2]) + P[9][2]);
-        double C[NR][NC];
-        double u[12], se;
-        double g3[3], z[3];
-        {
-            // ---- panel: three Householder steps on the own columns; v_k stays in P[k..9][k]; z = R_ee^-T d_e -----------
-            front_panel(P, de, g3, z);
-            pin(z[0]); pin(z[1]); pin(z[2]);
-            // ---- the reflectors on the odd-slot blocks and on c, one block at a time.  Slot s takes face s (lanes with
-            //      s < 3 - l) or face s - 1 (s > 3 - l).  Rows 0..2 of a finished block -> u = z^T R_eo (s = z . b_e for
-            //      c), rows 3..9 -> this lane's rows 0..6 of the 32 x 12 problem -----------------------------------------
-#define NIN_FACE_ROWS(B, R0, M, I)                                                                       \
-    _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                      \
-        B[R0][t] = (M) * nb0[I][t]; B[R0 + 1][t] = -((M) * sav[I][0][t]); B[R0 + 2][t] = -((M) * sav[I][1][t]); \
-    }
-#define NIN_TAKE_BLOCK(B, S)                                                                             \
-    _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                      \
-        u[3 * S + t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));                          \
-        pin(u[3 * S + t]);                                                                               \
-        _Pragma("unroll") for (int r = 0; r < 7; ++r) C[r][3 * S + t] = B[3 + r][t];                     \
-    }
-            {
-                double Bc[10][1];
-                Bc[0][0] = 1.0;                               // c = e_0 on entry: only the cell row carries a 1
-                apply_panel<1, true, false, false, false>(P, g3, Bc);
-                se = fma(z[2], Bc[2][0], fma(z[1], Bc[1][0], z[0] * Bc[0][0]));
-                pin(se);
-#pragma unroll
-                for (int r = 0; r < 7; ++r) C[r][12] = Bc[3 + r][0];
-            }
-            __builtin_amdgcn_sched_barrier(0);   // one block at a time: hoisted block set-ups cost registers
-            {
-                double B[10][3];
-                NIN_FACE_ROWS(B, 1, mA0, 0)
-                apply_panel<3, false, true, false, false>(P, g3, B);
-                NIN_TAKE_BLOCK(B, 0)
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                double B[10][3];
-                NIN_FACE_ROWS(B, 1, mB1, 0)
-                NIN_FACE_ROWS(B, 4, mA1, 1)
-                apply_panel<3, false, true, true, false>(P, g3, B);
-                NIN_TAKE_BLOCK(B, 1)
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                double B[10][3];
-                NIN_FACE_ROWS(B, 4, mB2, 1)
-                NIN_FACE_ROWS(B, 7, mA2, 2)
-                apply_panel<3, false, false, true, true>(P, g3, B);
-                NIN_TAKE_BLOCK(B, 2)
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                double B[10][3];
-                NIN_FACE_ROWS(B, 7, mB3, 2)
-                apply_panel<3, false, false, false, true>(P, g3, B);
-                NIN_TAKE_BLOCK(B, 3)
-            }
-#undef NIN_FACE_ROWS
-#undef NIN_TAKE_BLOCK
-        }
-        // row 7: the cell row of O_l, (x_K - x_v) on the columns of odd slot l, c = 1
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double ms = (l == s) ? 1.0 : 0.0;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) C[7][3 * s + t] = ms * dod[t];
-        }
-        C[7][12] = 1.0;
-
-        // ---- phase 2: 32 x 12 over the quad ------------------------------------------------------------------
-        NIN_MF_STAMP();                                   // 2: phase 1 done
-        nx.level1(g);   // next pass: CSR row starts, node coordinates, flags
-        double rinvq[3] = {0.0, 0.0, 0.0};
-        P2Loop<0, 6>::run(C, rinvq, l);
-        NIN_MF_STAMP();                                   // 3: phase 2, steps 0-5
-        nx.level2(g);   // next pass: cell and face ids
-        P2Loop<6, 12>::run(C, rinvq, l);
-        NIN_MF_STAMP();                                   // 4: phase 2 done
-        // next pass: geometry and permeability.  Issued HERE: the registers phase 2 has just released take them, and
-        // the back-substitution and the weights below (~2.5 k cycles, mostly dependent chains) cover their latency
-        __builtin_amdgcn_sched_barrier(0);
-        nx.level3(g);
-        __builtin_amdgcn_sched_barrier(0);
-        double y[12], t3[3] = {C[0][12], C[1][12], C[2][12]};
-        NIN_MF_STAMP();                                   // 5: geometry of the next pass requested
-        BackLoop<11>::run(C, rinvq, t3, y, l);
-        NIN_MF_STAMP();                                   // 6: back-substitution done
-        double tail = 0.0;
-#pragma unroll
-        for (int r = 3; r < NR; ++r) tail = fma(C[r][12], C[r][12], tail);
-        const double rr = quad_sum(tail);                        // r . r = |(Q^T c)(24:44)|^2
-
-        // ---- residuals on the two cell rows of this lane, weights ----------------------------------------------
-        double re = 1.0 - se;                                    // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_odd
-#pragma unroll
-        for (int j = 0; j < 12; ++j) re = fma(u[j], y[j], re);
-        double dots[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dots[s] = fma(dod[2], y[3 * s + 2], fma(dod[1], y[3 * s + 1], dod[0] * y[3 * s]));
-        const double dsel = (l == 0) ? dots[0] : (l == 1) ? dots[1] : (l == 2) ? dots[2] : dots[3];
-        const double ro = 1.0 - dsel;
-        const double rri = fast_rcp(rr);
-        double we = re * rri, wo = ro * rri;
-        // rank-deficient system (or NaN from a zero column): undefined in the reference, the zero row here.
-        // (isfinite, not w - w == 0: with the product above, contraction turns that into fma(re, rri, -w) != 0)
-        const bool ok = rr > 0.0;
-        we = (ok && __builtin_isfinite(we)) ? we : 0.0;
-        wo = (ok && __builtin_isfinite(wo)) ? wo : 0.0;
-
-        // ---- out: the node's 8 weights in esup order, written as 16-byte pieces ---------------------------------
-        wbuf[nd * 8 + (dsc & 7)] = we;
-        wbuf[nd * 8 + ((dsc >> 3) & 7)] = wo;
-        wave_lds_sync();
-        // gls.pyx:470-472 (only if an interior node carries the Neumann flag): neumann_ws = the last cell's weight
-        const double nwv = is_neu ? wbuf[nd * 8 + 7] : 0.0;
-        const double addv = add_neumann ? nwv : 0.0;
-        const double o0 = wbuf[nd * 8 + 2 * l] + addv, o1 = wbuf[nd * 8 + 2 * l + 1] + addv;
-        if (valid) {
-            out[eb + 2 * l] = o0;
-            out[eb + 2 * l + 1] = o1;
-            if (l == 0) nws[p] = nwv;
-        }
-        wave_lds_sync();
-        NIN_MF_STAMP();                                   // 7: weights stored
-#ifdef NIN_MF_STAMPS
-        if (blockIdx.x == 0 && threadIdx.x == 0 && ++pass_no == NIN_MF_STAMP_PASS)
-            for (int i = 0; i < 8; ++i) nws[nodes[i]] = (double)(stamps[i] - stamps[0]);   // (diagnostic build: clobbers neumann_ws of the first 8 listed nodes)
-#endif
-        cur = nx;
-        wg = wg_next;
-        wg_next = wg_lo + (int32_t)__builtin_amdgcn_readfirstlane(nx.ticket);
-    }
-}
-
-// ---- the same node on TWO wavefronts per SIMD (round 3: the default; the kernel above stays behind NIN_HEX8_ONE_WAVE) --------
+// ---- the node on TWO wavefronts per SIMD (round 3; round 2's one-wave-per-SIMD kernel -- in-flight loads hidden from the compiler behind
+//      inline-asm AGPR destinations and a manual s_waitcnt -- was deleted in round 4: correct, 25 % slower, and one compiler bump away from
+//      spilling such a destination) --------
 // A lone wavefront cannot keep the FP64 pipe busy (tools/micro_mfma64.hip: one wave issues a v_fma_f64 every 8.5 cycles, two
 // waves together one every 5.9), and the kernel above is one wave per SIMD because its peak -- the end of phase 1, where the
 // finished fill rows, the panel, a block in flight and the face records coexist -- is ~340 registers.  This one fits 256:
@@ -662,9 +265,15 @@ __global__ __launch_bounds__(256, 2) void nin_gls_hex8w2_kernel(GridView g, cons
     w2_stage_b(g, row_p[lane], rows_n);
     w2_dma_wait();
     w2_stage_c(g, rows_n[lane], rows_n[64 + lane], row_dsc[lane], rows_n);
-#ifdef NIN_MF_STAMPS
+#ifdef NIN_MF_STAMPS     // diagnostic build (tools/stamps_hex8mf.py): s_memtime at the phase boundaries of one pass
+#ifndef NIN_MF_STAMP_PASS
+#define NIN_MF_STAMP_PASS 8
+#endif
     unsigned long long stamps[8];
     int n_stamp = 0, pass_no = 0;
+#define NIN_MF_STAMP() do { if (n_stamp < 8) { __builtin_amdgcn_sched_barrier(0); stamps[n_stamp++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define NIN_MF_STAMP() do { } while (0)
 #endif
 #ifdef NIN_W2_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
@@ -938,41 +547,32 @@ int launch_hex8_desc(const GridView &g, const int32_t *nodes, int32_t count, int
 int launch_gls_hex8mf(const GridView &g, const int32_t *nodes, const int32_t *desc, int32_t count, int add_neumann,
                       double *out, double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
-    if (getenv("NIN_HEX8_ONE_WAVE") == nullptr) {   // (A/B switch: the one-wave-per-SIMD kernel of round 2)
-        int64_t blocks = ((int64_t)count + 4 * NPW - 1) / (4 * NPW);
-        const char *cap_env = getenv("NIN_W2_BLOCKS");   // (experiments)
-        const int64_t cap2 = cap_env ? atoll(cap_env) : 512;
-        if (blocks > cap2) blocks = cap2;            // two 4-wave workgroups per CU are resident (256 registers, 74 KB of LDS each)
-        if (blocks > 8) blocks &= ~(int64_t)7;
-        if (getenv("NIN_DEBUG_OCCUPANCY") != nullptr) {
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nin_gls_hex8w2_kernel<false>, 256, 0);
-            fprintf(stderr, "nin_gls_hex8w2_kernel: %d workgroups per CU, %lld launched\n", nb, (long long)blocks);
-        }
-        hipLaunchKernelGGL(nin_gls_hex8w2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count, add_neumann, out, nws, queue,
-                           nullptr, 0, nullptr);
-#ifdef NIN_W2_TRACE
-        if (getenv("NIN_W2_TRACE_FILE") != nullptr) {
-            static int calls = 0;
-            if (++calls == 6) {
-                (void)hipStreamSynchronize(stream);
-                static unsigned long long host[4096 * 4];
-                (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(nin_w2_trace), sizeof(host));
-                FILE *f = fopen(getenv("NIN_W2_TRACE_FILE"), "w");
-                for (int64_t b = 0; b < blocks * 4 && b < 4096; ++b)
-                    fprintf(f, "%lld %llu %llu %llx %llu\n", (long long)b, host[4 * b], host[4 * b + 1], host[4 * b + 2], host[4 * b + 3]);
-                fclose(f);
-            }
-        }
-#endif
-        return hipGetLastError() == hipSuccess ? 0 : -3;
-    }
     int64_t blocks = ((int64_t)count + 4 * NPW - 1) / (4 * NPW);
-    const int64_t cap = 256;   // 512 registers per lane: one 4-wave workgroup per CU is resident; persistent, blockIdx % 8 = XCD
-    if (blocks > cap) blocks = cap;
+    const char *cap_env = getenv("NIN_W2_BLOCKS");   // (experiments)
+    const int64_t cap2 = cap_env ? atoll(cap_env) : 512;
+    if (blocks > cap2) blocks = cap2;            // two 4-wave workgroups per CU are resident (256 registers, 74 KB of LDS each)
     if (blocks > 8) blocks &= ~(int64_t)7;
-    hipLaunchKernelGGL(nin_gls_hex8mf_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count,
-                       add_neumann, out, nws, queue);
+    if (getenv("NIN_DEBUG_OCCUPANCY") != nullptr) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nin_gls_hex8w2_kernel<false>, 256, 0);
+        fprintf(stderr, "nin_gls_hex8w2_kernel: %d workgroups per CU, %lld launched\n", nb, (long long)blocks);
+    }
+    hipLaunchKernelGGL(nin_gls_hex8w2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, g, nodes, desc, count, add_neumann, out, nws, queue,
+                       nullptr, 0, nullptr);
+#ifdef NIN_W2_TRACE
+    if (getenv("NIN_W2_TRACE_FILE") != nullptr) {
+        static int calls = 0;
+        if (++calls == 6) {
+            (void)hipStreamSynchronize(stream);
+            static unsigned long long host[4096 * 4];
+            (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(nin_w2_trace), sizeof(host));
+            FILE *f = fopen(getenv("NIN_W2_TRACE_FILE"), "w");
+            for (int64_t b = 0; b < blocks * 4 && b < 4096; ++b)
+                fprintf(f, "%lld %llu %llu %llx %llu\n", (long long)b, host[4 * b], host[4 * b + 1], host[4 * b + 2], host[4 * b + 3]);
+            fclose(f);
+        }
+    }
+#endif
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -989,6 +589,6 @@ int launch_gls_hex8mf_apply(const GridView &g, const int32_t *nodes, const int32
 }
 
 // (as rocprofv3 prints it: the weights form of the two-wave kernel is the instantiation <false>, the apply form <true>)
-const char *kernel_name_gls_hex8mf() { return getenv("NIN_HEX8_ONE_WAVE") == nullptr ? "nin_gls_hex8w2_kernel<false>" : "nin_gls_hex8mf_kernel"; }
+const char *kernel_name_gls_hex8mf() { return "nin_gls_hex8w2_kernel<false>"; }
 
 }  // namespace nin

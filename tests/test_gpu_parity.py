@@ -200,13 +200,10 @@ def test_gpu_generic_kernel_on_hex(oracle_lib, monkeypatch, no_mfw):
     assert util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL
 
 
-@pytest.mark.parametrize("one_wave", [False, True])
-def test_gpu_cube_kernel_forms(oracle_lib, monkeypatch, one_wave):
-    """The cube-node kernel in both forms against the oracle: two wavefronts per SIMD (round 3's default: blocks a column at a
-    time, fill entries parked in LDS, index levels of the next pass by LDS-DMA) and round 2's one-wavefront kernel behind
-    NIN_HEX8_ONE_WAVE.  More groups than resident waves, a ragged last group, a Neumann plane, target subsets."""
-    if one_wave:
-        monkeypatch.setenv("NIN_HEX8_ONE_WAVE", "1")
+def test_gpu_cube_kernel_forms(oracle_lib, monkeypatch):
+    """The cube-node kernel against the oracle: two wavefronts per SIMD (blocks a column at a time, fill entries parked in LDS, index
+    levels of the next pass by LDS-DMA; round 2's one-wavefront kernel was deleted in round 4).  More groups than resident waves, a
+    ragged last group, a Neumann plane, target subsets."""
     mesh = M.hex_mesh(41, 37, 29, jitter=0.15, seed=6)
     M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(1, 0.0), seed=3)
     o = oracle_lib.OracleInterpolator("port", threads=16)
@@ -604,7 +601,6 @@ def test_gpu_gls_degenerate_set(oracle_lib, kind):
 # every way a node can reach a GLS kernel: name -> environment switches (read when the launch plan is built)
 _GLS_ROUTES = {
     "default": (),                                                        # cube-node kernel / mfw strips (two-coloured) / the wide kernel / small, quad, block for the boundary
-    "cube_kernel_one_wave": ("NIN_HEX8_ONE_WAVE",),                       # round 2's cube-node kernel (one wavefront per SIMD) instead of the two-wave form
     "no_cube_kernel": ("NIN_GLS_NO_GROUP",),                              # cube nodes -> mfw small instantiation
     "mfw_lane_columns": ("NIN_GLS_NO_GROUP", "NIN_MFW_LANE_COLUMNS"),     # the mfw kernel's first form
     "mfw_row_lanes": ("NIN_MFW_NO_STRIPS",),                              # its second form (round 2's default) where the strip form runs now

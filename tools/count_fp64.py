@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "ninpol_amd", "csrc", "kernels_gls_hex8mf.hip")
-kern = sys.argv[2] if len(sys.argv) > 2 else "nin_gls_hex8mf_kernel"
+kern = sys.argv[2] if len(sys.argv) > 2 else "nin_gls_hex8w2_kernelILb0"
 lanes_per_node = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 asm = "/tmp/_count_fp64.s"
 sys.path.insert(0, ROOT)

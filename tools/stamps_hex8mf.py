@@ -1,5 +1,5 @@
-"""Per-phase s_memtime stamps of one pass (16 nodes) of the cube-node kernel -- nin_gls_hex8w2_kernel, or round 2's
-nin_gls_hex8mf_kernel under NIN_HEX8_ONE_WAVE=1 --, wave 0 of workgroup 0, pass NIN_MF_STAMP_PASS (default 8)
+"""Per-phase s_memtime stamps of one pass (16 nodes) of the cube-node kernel, nin_gls_hex8w2_kernel (round 2's one-wave kernel is
+gone since round 4), wave 0 of workgroup 0, pass NIN_MF_STAMP_PASS (default 8)
 (needs a -DNIN_MF_STAMPS build of kernels_gls_hex8mf.hip; the build clobbers neumann_ws of the first 8 cube nodes):
     bash tools/build_variant.sh stamps kernels_gls_hex8mf.hip -DNIN_MF_STAMPS
     NINPOL_AMD_LIB=tools/_bin/lib_stamps.so python tools/stamps_hex8mf.py [edge]
@@ -19,11 +19,7 @@ for _ in range(3): plan.launch(out.data_ptr(), nws.data_ptr(), st.cuda_stream)
 torch.cuda.synchronize()
 first = np.nonzero(np.asarray(I.grid.boundary_points) == 0)[0][:8]      # the first 8 interior (= cube) nodes
 s = nws.cpu().numpy()[first]
-if os.environ.get("NIN_HEX8_ONE_WAVE"):
-    names = ["face rows (+ wait for the prefetched geometry)", "phase 1 (panel + blocks)", "phase 2, steps 0-5", "phase 2, steps 6-11",
-             "request of the next geometry", "back-substitution", "residuals, weights, stores"]
-else:
-    names = ["ids in (LDS-DMA), geometry loads, face rows", "phase 1 (panel + 10 columns)", "tile put together (LDS, selects)",
-             "phase 2, steps 0-5", "phase 2, steps 6-11", "back-substitution", "residuals, weights, stores"]
+names = ["ids in (LDS-DMA), geometry loads, face rows", "phase 1 (panel + 10 columns)", "tile put together (LDS, selects)",
+         "phase 2, steps 0-5", "phase 2, steps 6-11", "back-substitution", "residuals, weights, stores"]
 for i in range(7): print(f"{names[i]:50s} {s[i + 1] - s[i]:8.0f} cycles")
 print(f"{'pass (16 nodes)':50s} {s[7]:8.0f} cycles")
