@@ -1,5 +1,5 @@
-"""The fronts of unstructured nodes: on the interior nodes of a Delaunay mesh, (1) the largest greedy independent set of
-3-face cells (one greedy pass per starting cell: what mfx_desc.hpp computes) against the exact maximum (branch and bound), (2) the size
+"""The fronts of unstructured nodes: on the interior nodes of a Delaunay mesh, (1) the independent set of 3-face cells
+mfx_desc.hpp computes (minimum-degree greedy) against mfw_desc.hpp's first-fit greedy and the exact maximum (branch and bound), (2) the size
 class of the dense problem each node falls into.  CPU only:   python tools/front_sets.py [n] [lattice]"""
 import collections
 import os
@@ -53,6 +53,26 @@ def greedy(adj):
     return bin(best).count("1")
 
 
+def mindeg(adj):
+    """what mfx_desc.hpp computes: minimum-residual-degree greedy from every fourth starting cell, the best kept"""
+    ne, best = len(adj), 0
+    elig = sum(1 << c for c in range(ne) if bin(adj[c]).count("1") == 3)
+    for s in range(0, ne, 4):
+        avail, n = elig, 0
+        while avail and n < 16:
+            pick, pd = -1, 99
+            for k in range(ne):
+                c = (s + k) % ne
+                if (avail >> c) & 1:
+                    d = bin(adj[c] & avail).count("1")
+                    if d < pd:
+                        pd, pick = d, c
+            avail &= ~(adj[pick] | (1 << pick))
+            n += 1
+        best = max(best, n)
+    return best
+
+
 def exact(adj):
     best = [0]
 
@@ -91,15 +111,17 @@ by_ne, classes = collections.defaultdict(list), collections.Counter()
 for p in np.nonzero(interior)[0][:3000]:
     adj = graph(int(p))
     ne, nf = len(adj), sum(bin(a).count("1") for a in adj) // 2
-    g = greedy(adj)
-    by_ne[ne].append((g, exact(adj)))
+    g = mindeg(adj)
+    by_ne[ne].append((greedy(adj), g, exact(adj)))
     F = min(g, 16)
     D, nfree = ne - F, nf - 3 * F
     classes[size_class(F, D, nfree) if D <= 21 and nfree <= 16 else "block"] += 1
 print(f"Delaunay {lattice} cloud n = {n}: {sum(len(v) for v in by_ne.values())} interior nodes")
-print("cells  nodes  greedy fronts (mean)  exact maximum (mean)  exact - greedy")
+print("cells  nodes  first-fit greedy (mfw_desc)  min-degree greedy (mfx_desc)  exact maximum   (mean fronts)")
 for ne in sorted(by_ne):
     a = np.array(by_ne[ne])
-    print(f"{ne:5d} {len(a):6d} {a[:, 0].mean():12.2f} {a[:, 1].mean():22.2f} {(a[:, 1] - a[:, 0]).mean():14.2f}")
+    print(f"{ne:5d} {len(a):6d} {a[:, 0].mean():16.2f} {a[:, 1].mean():28.2f} {a[:, 2].mean():22.2f}")
+a = np.concatenate([np.array(v) for v in by_ne.values()])
+print(f"  all {len(a):6d} {a[:, 0].mean():16.3f} {a[:, 1].mean():28.3f} {a[:, 2].mean():22.3f}")
 tot = sum(classes.values())
 print("size classes of the dense problem:", {k: f"{100 * v / tot:.1f} %" for k, v in sorted(classes.items())})
