@@ -61,8 +61,9 @@ PLAN_KERNEL_NAMES = {   # kernel of the launch plan -> its name in a rocprofv3 t
     "block8": "nin_gls_block_kernel<8, *>", "scratch": "nin_gls_wave_kernel", "hex8": "nin_gls_hex8w2_kernel",
     "mfw_large": "nin_gls_mfw_kernel<12, 12, true, false, true>", "mfw_small": "nin_gls_mfw_kernel<6, 6, true, false, false>",
     "mfw_general": "nin_gls_mfw_kernel<12, 15, true, true, false>", "small4": "nin_gls_small_kernel<4>",
-    "small8": "nin_gls_small_kernel<8>", "small12": "nin_gls_small_kernel<12>", "quad4": "nin_gls_quad4_kernel", "mfx_6x10": "nin_gls_mfx_kernel<6, 10>", "mfx_7x11": "nin_gls_mfx_kernel<7, 11>",
-    "mfx_8x13": "nin_gls_mfx_kernel<8, 13>", "mfx_9x15": "nin_gls_mfx_kernel<9, 15>", "mfx_10x16": "nin_gls_mfx_kernel<10, 16>"}
+    "small8": "nin_gls_small_kernel<8>", "small12": "nin_gls_small_kernel<12>", "quad4": "nin_gls_quad4_kernel", "mfx_6x10": "nin_gls_mfx_kernel<6, 10, false>", "mfx_7x11": "nin_gls_mfx_kernel<7, 11, false>",
+    "mfx_8x13": "nin_gls_mfx_kernel<8, 13, false>", "mfx_9x15": "nin_gls_mfx_kernel<9, 15, false>", "mfx_10x16": "nin_gls_mfx_kernel<10, 16, false>",
+    "mfx_boundary": "nin_gls_mfx_kernel<7, 11, true>"}
 
 
 def gls_kernel_rows(grid, launch, time_launches, reps=3):
@@ -615,7 +616,7 @@ def main():
                     n_int = int((~np.asarray(Io.grid.boundary_points).astype(bool)).sum())
                     pl = Io.grid.gls_plan()
                     row["interior_nodes_off_the_block_kernel"] = round(
-                        (pl["hex8"] + pl["mfw_large"] + pl["mfw_small"] + pl["mfw_general"] + pl["mfx"]) / max(n_int, 1), 4)
+                        (pl["hex8"] + pl["mfw_large"] + pl["mfw_small"] + pl["mfw_general"] + pl["mfx"]) / max(n_int, 1), 4)   # (pl["mfx"]: interior classes only)
                     rows[name] = row
                     del Io, mo
                     torch.cuda.empty_cache()

@@ -484,6 +484,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
                           (getenv("NIN_GLS_NO_SMALL") == nullptr ? 8 : 0) |         // (bit 3: the one-wavefront dense kernel for small nodes)
                           (getenv("NIN_GLS_NO_QUAD4") == nullptr ? 16 : 0) |        // (bit 4: the two-lanes-per-node kernel for quad nodes)
                           (getenv("NIN_GLS_NO_MFX") == nullptr ? 32 : 0) |          // (bit 5: the wide multifrontal kernel: unstructured meshes)
+                          (getenv("NIN_GLS_MFX_NO_BOUNDARY") != nullptr ? 128 : 0) | // (bit 7: ... leaves the boundary nodes to the block kernel: round 3's route)
                           (getenv("NIN_GLS_MFW_GENERAL") == nullptr ? 64 : 0);      // (bit 6: ... takes the general kind's nodes too -- the default
                                                                                     //  since its dense phase runs straight-line per size class: 37 against
                                                                                     //  38 ns a node on a Delaunay mesh, equal on the mixed mesh; NIN_GLS_MFW_GENERAL=1
@@ -513,6 +514,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         else if (c >= 249 && c <= 251) small_list[c - 249].push_back((int32_t)p);
         else if (c == 248) quad4_list.push_back((int32_t)p);
         else if (c >= 243 && c <= 247) mfx_list[c - 243].push_back((int32_t)p);
+        else if (c == 242) mfx_list[5].push_back((int32_t)p);
         else lists[c].push_back((int32_t)p);
     }
     for (int c = 0; c < kGlsClasses; ++c) {
@@ -720,7 +722,7 @@ static int launch_gls_but_cube(DeviceGrid &d, int add_neumann, double *out, doub
     for (int i = 0; i < 3 && !rc; ++i)
         if (on(9 + i)) rc = launch_gls_small(d.v, d.small[i].nodes, d.small[i].count, i, add_neumann, out, nws, stream);
     if (!rc && on(12)) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, out, nws, stream);
-    for (int i = 0; i < DeviceGrid::kMfxLists && !rc; ++i)   // (work counters: ints 8 .. 12)
+    for (int i = 0; i < DeviceGrid::kMfxLists && !rc; ++i)   // (work counters: ints 8 .. 13)
         if (on(13 + i)) rc = launch_gls_mfx(d.v, d.mfx[i].nodes, d.mfx_desc[i], d.mfx[i].count, i, add_neumann, out, nws, d.gls_queue + 8 + i, stream);
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         if ((c == kGlsClasses - 1 && d.side_pending) || !on(c)) continue;
@@ -775,6 +777,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else if (c >= 249 && c <= 251) c = kGlsClasses + 4 + (c - 249);   // the small-node kernel, kind 0 / 1 / 2
         else if (c == 248) c = kGlsClasses + 7;                           // the quad-node kernel
         else if (c >= 243 && c <= 247) c = kGlsClasses + 8 + (c - 243);   // the wide multifrontal kernel, by size class
+        else if (c == 242) c = kGlsClasses + 8 + 5;                       // ... its boundary nodes
         lists[c].push_back((int32_t)targets[i]);
     }
     // one device buffer for all class lists, filled before the first launch: a per-class allocate / copy / free
@@ -1249,10 +1252,10 @@ double hh_flops(int64_t m, int64_t n_pivot, int64_t n_cols) {
 }
 // fronts of 3-face cells + a dense rest (kernels_gls_hex8mf / mfw / mfx): F fronts, D dense cells, `faces` internal faces of which
 // `free_faces` join two dense cells
-double multifrontal_flops(int64_t F, int64_t D, int64_t faces, int64_t free_faces) {
-    const double face = 52.0 * faces;
+double multifrontal_flops(int64_t F, int64_t D, int64_t faces, int64_t free_faces, int64_t neumann_rows = 0) {
+    const double face = 52.0 * faces + 15.0 * neumann_rows;
     const double p1 = F * (hh_flops(10, 3, 3 + 9 + 1) + 9 + 54 + 6);
-    const int64_t m2 = 7 * F + D + 3 * free_faces, n2 = 3 * D;
+    const int64_t m2 = 7 * F + D + 3 * free_faces + neumann_rows, n2 = 3 * D;
     const double p2 = hh_flops(m2, n2, n2 + 1);
     const double tail = (double)n2 * n2 + F * (2 * 9 + 2) + D * (2 * 3 + 1) + 2 * (m2 - n2) + (F + D) + 1;
     return face + p1 + p2 + tail;
@@ -1267,7 +1270,7 @@ double dense_flops(int64_t ne, int64_t n_if, int64_t n_nb) {
 double dgels_flops(double m, double n, double nrhs) { return 2 * m * n * n - 2 * n * n * n / 3 + nrhs * (4 * m * n - 2 * n * n) + nrhs * n * n; }
 }  // namespace
 
-int nin_gls_plan_flops(nin_grid *g, double alg[18], double ref[18], int64_t computed[18]) {
+int nin_gls_plan_flops(nin_grid *g, double alg[19], double ref[19], int64_t computed[19]) {
     if (!g || !alg || !ref || !computed) return fail(NIN_EINVAL, "NULL argument");
     DeviceGrid &d = g->d;
     HostGrid &h = g->h;
@@ -1275,7 +1278,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[18], double ref[18], int64_t comp
     if (!d.fields_set || !d.flag_staging) return fail(NIN_ESTATE, "nin_fields_set has not been called (the Neumann flags decide which boundary nodes are computed)");
     if (h.ensure(A_ESUP_PTR | A_ESUP | A_FSUP_PTR | A_FSUP | A_ESUF)) return fail(NIN_EHIP, "mirroring the connectivity failed");
     HIP_TRY(hipSetDevice(d.device));
-    for (int k = 0; k < 18; ++k) { alg[k] = ref[k] = 0.0; computed[k] = 0; }
+    for (int k = 0; k < 19; ++k) { alg[k] = ref[k] = 0.0; computed[k] = 0; }
     const int64_t P = h.n_points;
     // (F, D, free faces) of the nodes of the multifrontal kernels: from their descriptors
     std::vector<uint32_t> fdq((size_t)P, 0u);
@@ -1285,7 +1288,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[18], double ref[18], int64_t comp
         std::vector<uint32_t> hd((size_t)count * words);
         if (hipMemcpy(hn.data(), nodes, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) return -3;
         if (hipMemcpy(hd.data(), desc, hd.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -3;
-        for (int32_t i = 0; i < count; ++i) fdq[hn[i]] = hd[(size_t)i * words + word] & 0xFFFFFFu;
+        for (int32_t i = 0; i < count; ++i) fdq[hn[i]] = hd[(size_t)i * words + word] & 0xFFFFFFu;   // (F, D, free faces: the low 24 bits of either kind's word)
         return 0;
     };
     for (int i = 0; i < 3; ++i)
@@ -1294,7 +1297,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[18], double ref[18], int64_t comp
         if (read_desc(d.mfx[i].nodes, d.mfx_desc[i], d.mfx[i].count, kMfxDescWords, 0)) return fail(NIN_EHIP, "reading the descriptors back failed");
     for (int64_t p = 0; p < P; ++p) {
         const int c = g->node_class[p];
-        const int k = c == 255 ? 5 : (c >= 252 && c <= 254) ? 6 + (254 - c) : (c >= 249 && c <= 251) ? 9 + (c - 249) : c == 248 ? 12 : (c >= 243 && c <= 247) ? 13 + (c - 243) : c;
+        const int k = c == 255 ? 5 : (c >= 252 && c <= 254) ? 6 + (254 - c) : (c >= 249 && c <= 251) ? 9 + (c - 249) : c == 248 ? 12 : (c >= 243 && c <= 247) ? 13 + (c - 243) : c == 242 ? 18 : c;
         const int fl = d.flag_staging[p];
         if ((fl & 1) && !(fl & 2)) continue;                   // a Dirichlet boundary node: the zero row, nothing computed (gls.pyx:165-166)
         const int64_t eb = h.esup_ptr[p], ne = h.esup_ptr[p + 1] - eb, fb = h.fsup_ptr[p], nf = h.fsup_ptr[p + 1] - fb;
@@ -1311,7 +1314,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[18], double ref[18], int64_t comp
         if (k == 5) alg[k] += multifrontal_flops(4, 4, 12, 0);
         else if ((k >= 6 && k <= 8) || k >= 13) {
             const uint32_t w = fdq[p];
-            alg[k] += multifrontal_flops(w & 255u, (w >> 8) & 255u, n_if, (w >> 16) & 255u);
+            alg[k] += multifrontal_flops(w & 255u, (w >> 8) & 255u, n_if, (w >> 16) & 255u, k >= 13 ? n_nb : 0);
         } else if (k == 12) {
             // two fronts of 8 rows (cell row, two internal faces, the Neumann row) x (3 | 6 | c), then 14 x 6 over the pair
             alg[k] += 52.0 * 4 + 15.0 * 4 + 2 * (hh_flops(8, 3, 3 + 6 + 1) + 9 + 36 + 6) + hh_flops(14, 6, 7) + 36 + 2 * 20 + 2 * 7 + 2 * 8 + 5;
@@ -1352,7 +1355,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[18], double ref[18], int64_t comp
     return NIN_OK;
 }
 
-int nin_gls_plan(const nin_grid *g, int64_t counts[18]) {
+int nin_gls_plan(const nin_grid *g, int64_t counts[19]) {
     if (!g || !counts) return fail(NIN_EINVAL, "NULL argument");
     if (g->d.device < 0 || g->d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
     for (int c = 0; c < kGlsClasses; ++c) counts[c] = g->d.gls[c].count;

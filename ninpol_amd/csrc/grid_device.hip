@@ -581,10 +581,14 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
         if (kind == 2 && (use_group & 4) && !small_fits && !(use_group & 64)) { node_class[p] = 252; return; }
     }
     // interior nodes of unstructured meshes: more cells than the kinds above hold, no two-colouring (kernels_gls_mfx.hip, mfx_desc.hpp)
-    if ((use_group & 32) && !force_global && nbf == 0 && ne <= kMfxMaxCells && !small_fits) {
+    // (round 4: boundary nodes too -- computed only when the variable flags them Neumann; their boundary faces are one row each)
+    const bool small_fits_b = (use_group & 8) && !force_global && g.dim == 3 && ne <= 12 && nf <= 48 && ne + 3 * (nf - nbf) + nbf <= 64;
+    if ((use_group & 32) && !force_global && ne <= kMfxMaxCells && !(nbf == 0 ? small_fits : small_fits_b) &&
+        (nbf == 0 || !(use_group & 128))) {
         uint32_t w[kMfxDescWords];
         const int k = mfx_descriptor(g, (int32_t)p, w);   // 1 + the size class of its dense problem
-        if (k > 0) { node_class[p] = (uint8_t)(243 + k - 1); return; }
+        if (k > 0 && nbf == 0) { node_class[p] = (uint8_t)(243 + k - 1); return; }
+        if (k > 0 && k <= 2) { node_class[p] = 242; return; }   // a boundary node that fits 7 x 11 tiles: the boundary instantiation's list
     }
     // nodes inside a boundary face of a hexahedron mesh: two lanes per node (kernels_gls_quad4.hip)
     if ((use_group & 16) && !force_global && ne == 4 && nf == 8 && nbf == 4 && g.dim == 3) {

@@ -35,7 +35,7 @@ using namespace mfwstrips;
 //     [0 0 0 | cell 1 (3) | cell 2 (3) | cell 3 (3) | c]
 // so that the entry of a column whose cell has code k in the row (0: not one of the row's cells) is at 3 k + component -- code 0
 // reads the zeros in front, no select.  A front's 7 fill rows have 3 cells, a free face's 3 rows 2, a dense cell's row 1 (c = 1).
-// Rows: 7 f + i (fill row i of front f), 7 F + d (dense cell d), 7 F + D + 3 q + k (row k of free face q).
+// Rows: 7 f + i (fill row i of front f), 7 F + d (dense cell d), 7 F + D + 3 q + k (row k of free face q), then one per boundary face.
 constexpr int XROW = 13;
 #ifndef NIN_MFX_TWO_WAVE_TILES
 #define NIN_MFX_TWO_WAVE_TILES 104     // classes of up to this many tiles run at two wavefronts per SIMD (256 registers: the 7 x 11 class spills 256 B,
@@ -53,8 +53,8 @@ struct XDims {
 
 // The dense phase of one node: gather the rows from the staging area into TQ x TCB tiles (16 rows x 4 columns each) and factor
 // (mfw_strips.hpp's unrolled strip_factor<TQ, TCB>: straight-line, sweeps the whole class size).
-template <int TQ, int TCB>
-__device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, int nc, int nrows, int F, int D, int nfree, int lane) {
+template <int TQ, int TCB, bool BND>
+__device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, int nc, int nrows, int F, int D, int nfree, int nbnd, int lane) {
     using Dm = XDims<TQ, TCB>;
     const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
     double C[TQ][TCB];
@@ -75,13 +75,13 @@ __device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, in
         const int row = 16 * q + 4 * sb + si;
         const bool fill = row < 7 * F;
         const int f = fill ? (row * 9363) >> 16 : 0, d = row - 7 * F, x = d - D;
-        const bool cell = d >= 0 && d < D, fre = x >= 0 && x < 3 * nfree;
-        const int qf = fre ? (x * 43) >> 7 : 0;
+        const bool cell = d >= 0 && d < D, fre = x >= 0 && x < 3 * nfree, bnd = BND && x >= 3 * nfree && x < 3 * nfree + nbnd;
+        const int qf = fre ? (x * 43) >> 7 : bnd ? x - 2 * nfree : 0;     // (a boundary face's entry lies behind the free faces': nfree + (x - 3 nfree))
         const uint32_t flo = (uint32_t)__shfl((int)tlo, f), fhi = (uint32_t)__shfl((int)thi, f);
         const uint32_t fw = dl[kMfxFree0 + qf];
-        const uint64_t qt = (1ull << (2 * ((fw >> 6) & 31u))) | (2ull << (2 * ((fw >> 11) & 31u)));
-        rtl[q] = fill ? flo : cell ? (d < 16 ? 1u << (2 * d) : 0u) : fre ? (uint32_t)qt : 0u;
-        rth[q] = fill ? fhi : cell ? (d >= 16 ? 1u << (2 * (d - 16)) : 0u) : fre ? (uint32_t)(qt >> 32) : 0u;
+        const uint64_t qt = (1ull << (2 * ((fw >> 6) & 31u))) | (bnd ? 0ull : 2ull << (2 * ((fw >> 11) & 31u)));
+        rtl[q] = fill ? flo : cell ? (d < 16 ? 1u << (2 * d) : 0u) : (fre || bnd) ? (uint32_t)qt : 0u;
+        rth[q] = fill ? fhi : cell ? (d >= 16 ? 1u << (2 * (d - 16)) : 0u) : (fre || bnd) ? (uint32_t)(qt >> 32) : 0u;
         const bool have = row < nrows;
         rbz[q] = have ? 8u * XROW * (uint32_t)row : 0u;
         rbc[q] = have ? 8u * (XROW * (uint32_t)row + 12u) : 8u * (uint32_t)Dm::Z;
@@ -112,7 +112,9 @@ __device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, in
     return strip_factor<TQ, TCB>(C, nc, lane, Rm, Dm::RP, ST);
 }
 
-template <int TQ, int TCB>
+// BND: the list holds BOUNDARY nodes (one instantiation, 7 x 11 tiles: a boundary node has half a node's cells): a Dirichlet one gets its
+// zero row at once (gls.pyx:165-166), a Neumann one one more row per boundary face.  The interior instantiations carry none of that code.
+template <int TQ, int TCB, bool BND>
 __global__ __launch_bounds__(64, (XDims<TQ, TCB>::WAVES)) void nin_gls_mfx_kernel(GridView g, const int32_t *__restrict__ nodes,
                                                                                  const uint32_t *__restrict__ desc, int32_t count,
                                                                                  int add_neumann, double *__restrict__ out,
@@ -136,10 +138,17 @@ __global__ __launch_bounds__(64, (XDims<TQ, TCB>::WAVES)) void nin_gls_mfx_kerne
         const uint32_t *dw = desc + (size_t)kMfxDescWords * idx;
         if (lane < kMfxDescWords) dl[lane] = dw[lane];
         const uint32_t fd = (uint32_t)__builtin_amdgcn_readfirstlane((int)dw[0]);
-        const int F = fd & 255, D = (fd >> 8) & 255, nfree = (fd >> 16) & 255, ne = F + D;
+        const int F = fd & 255, D = (fd >> 8) & 255, nfree = (fd >> 16) & 255, nbnd = BND ? (int)(fd >> 24) : 0, ne = F + D;
         const uint32_t eb = (uint32_t)__builtin_amdgcn_readfirstlane(g.esup_ptr[p]);
         const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane(g.fsup_ptr[p]);
-        const bool is_neu = (__builtin_amdgcn_readfirstlane((int)g.flags[p]) & 2) != 0;
+        const int flg = __builtin_amdgcn_readfirstlane((int)g.flags[p]);
+        const bool is_neu = (flg & 2) != 0;
+        if (BND && (flg & 1) && !is_neu) {                       // a Dirichlet boundary node (gls.pyx:165-166): the zero row, nothing computed
+            if (lane < ne) out[eb + lane] = 0.0;
+            if (lane == 0) nws[p] = 0.0;
+            wave_lds_sync();                                     // (the descriptor words of the next node go where this one's are being written)
+            continue;
+        }
         const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1], xv2 = g.coords[3 * (size_t)p + 2];
         wave_lds_sync();
         // phase 1 works with FOUR lanes per front: lane 4 f + j applies the front's reflectors to c (j = 0) or to the columns of
@@ -251,6 +260,22 @@ __global__ __launch_bounds__(64, (XDims<TQ, TCB>::WAVES)) void nin_gls_mfx_kerne
                 fs[2 * XROW + 6 + t] = Uv[t];
             }
             fs[0 * XROW + 12] = 0.0; fs[1 * XROW + 12] = 0.0; fs[2 * XROW + 12] = 0.0;
+        } else if (BND && lane < nfree + nbnd) {
+            // a boundary face of a Neumann node: ONE row, -(K N) on its cell's columns (gls.pyx:394-416; the right-hand side it carries
+            // in the reference sits in a column the last-row identity never reads)
+            const uint32_t fw = dl[kMfxFree0 + lane];
+            const uint32_t f = (uint32_t)g.fsup[fb + (fw & 63u)];
+            const uint32_t ca_ = (uint32_t)g.esup[eb + slotpos[(fw >> 6) & 31u]];
+            const double N0 = (double)g.face_normal[3 * (size_t)f + 0], N1 = (double)g.face_normal[3 * (size_t)f + 1],
+                         N2 = (double)g.face_normal[3 * (size_t)f + 2];
+            const double *Ka = g.perm + 9 * (size_t)ca_;
+            double *fs = Rm + XROW * (7 * F + D + 3 * nfree + (lane - nfree));
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                fs[t] = 0.0;
+                fs[3 + t] = -(Ka[t * 3 + 0] * N0 + Ka[t * 3 + 1] * N1 + Ka[t * 3 + 2] * N2);
+            }
+            fs[12] = 0.0;
         }
         // the dense cells' rows: (x_K - x_v) on the cell's own columns, c = 1
         if (lane < D) {
@@ -262,8 +287,8 @@ __global__ __launch_bounds__(64, (XDims<TQ, TCB>::WAVES)) void nin_gls_mfx_kerne
         wave_lds_sync();
 
         const int nc = 3 * D;                                  // the columns 0 .. nc - 1 are pivoted, column nc is c
-        const int nrows = 7 * F + D + 3 * nfree;
-        const double rr = dense_phase<TQ, TCB>(Rm, dl, nc, nrows, F, D, nfree, lane);
+        const int nrows = 7 * F + D + 3 * nfree + nbnd;
+        const double rr = dense_phase<TQ, TCB, BND>(Rm, dl, nc, nrows, F, D, nfree, nbnd, lane);
         wave_lds_sync();
         // ---- R y = (Q^T c)(0:nc) by columns: lane = row ------------------------------------------------------------------
         {
@@ -348,20 +373,21 @@ int launch_mfx_desc(const GridView &g, const int32_t *nodes, int32_t count, uint
 int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int cls, int add_neumann, double *out,
                    double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
-    if (cls < 0 || cls >= kMfxClasses) return -1;
+    if (cls < 0 || cls > kMfxClasses) return -1;         // (cls == kMfxClasses: the boundary nodes' list)
     int64_t blocks = count;
     // persistent: one wavefront per workgroup, one (class 0: two) per SIMD -- the register file of a SIMD lane belongs to one (two) node(s)
-    constexpr int tiles[kMfxClasses] = {6 * 10, 7 * 11, 8 * 13, 9 * 15, 10 * 16};
+    constexpr int tiles[kMfxClasses + 1] = {6 * 10, 7 * 11, 8 * 13, 9 * 15, 10 * 16, 7 * 11};
     const int64_t cap = 4 * 256 * (tiles[cls] <= NIN_MFX_TWO_WAVE_TILES ? 2 : 1);
     if (blocks > cap) blocks = cap;
-#define NIN_MFX_LAUNCH(TQ, TCB)                                                                                                      \
-    hipLaunchKernelGGL((nin_gls_mfx_kernel<TQ, TCB>), dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, desc, count, add_neumann, out, \
+#define NIN_MFX_LAUNCH(TQ, TCB, BND)                                                                                                      \
+    hipLaunchKernelGGL((nin_gls_mfx_kernel<TQ, TCB, BND>), dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, desc, count, add_neumann, out, \
                        nws, queue)
-    if (cls == 0) NIN_MFX_LAUNCH(6, 10);
-    else if (cls == 1) NIN_MFX_LAUNCH(7, 11);
-    else if (cls == 2) NIN_MFX_LAUNCH(8, 13);
-    else if (cls == 3) NIN_MFX_LAUNCH(9, 15);
-    else NIN_MFX_LAUNCH(10, 16);
+    if (cls == 0) NIN_MFX_LAUNCH(6, 10, false);
+    else if (cls == 1) NIN_MFX_LAUNCH(7, 11, false);
+    else if (cls == 2) NIN_MFX_LAUNCH(8, 13, false);
+    else if (cls == 3) NIN_MFX_LAUNCH(9, 15, false);
+    else if (cls == 4) NIN_MFX_LAUNCH(10, 16, false);
+    else NIN_MFX_LAUNCH(7, 11, true);
 #undef NIN_MFX_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

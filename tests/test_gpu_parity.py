@@ -424,7 +424,7 @@ def test_gpu_wide_multifrontal_kernel_on_unstructured_tetrahedra(oracle_lib, mon
     o.load_mesh(mesh)
     wo, no = o.prepare("gls", "u")
     plans = {}
-    for route in ("default", "NIN_GLS_MFW_GENERAL", "NIN_GLS_NO_MFX"):
+    for route in ("default", "NIN_GLS_MFW_GENERAL", "NIN_GLS_NO_MFX", "NIN_GLS_MFX_NO_BOUNDARY"):
         if route != "default":
             monkeypatch.setenv(route, "1")
         I = _interp()
@@ -442,6 +442,10 @@ def test_gpu_wide_multifrontal_kernel_on_unstructured_tetrahedra(oracle_lib, mon
     # (the interior nodes the block kernel keeps: more than 16 + 21 cells -- the random cloud has a few per cent of them)
     assert one_wave(plans["default"]) >= (0.95 if lattice == "bcc" else 0.85) * n_interior, (plans["default"], n_interior)
     assert one_wave(plans["NIN_GLS_NO_MFX"]) < one_wave(plans["default"])
+    # the Neumann plane's nodes (half a node's cells, boundary faces as one row each): the wide kernel's boundary instantiation by
+    # default, the block / small-node kernels with NIN_GLS_MFX_NO_BOUNDARY (round 3's route) -- same weights either way (above)
+    assert plans["default"]["mfx_boundary"] > 0 and plans["NIN_GLS_MFX_NO_BOUNDARY"]["mfx_boundary"] == 0
+    assert plans["NIN_GLS_MFX_NO_BOUNDARY"]["mfx"] == plans["default"]["mfx"]
 
 
 def test_gpu_wide_kernel_dense_phase_alone():
@@ -611,6 +615,7 @@ _GLS_ROUTES = {
     "no_quad_kernel": ("NIN_GLS_NO_QUAD4",),                              # nodes inside a boundary face -> small-node kernel
     "no_small_kernel": ("NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4"),          # boundary nodes -> block kernel (round 2's route)
     "small_where_it_fits": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW"),        # the small-node kernel for every node of <= 12 cells and <= 64 rows
+    "no_boundary_in_wide": ("NIN_GLS_MFX_NO_BOUNDARY",),                  # boundary nodes beyond the small-node kernel -> block kernel (round 3's route)
     "block_only": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_NO_MFX", "NIN_GLS_NO_SMALL", "NIN_GLS_NO_QUAD4"),   # block kernel, 1 / 2 / 4 / 8 wavefronts per node
     "global_scratch": ("NIN_GLS_NO_GROUP", "NIN_GLS_NO_MFW", "NIN_GLS_FORCE_GLOBAL"),   # the wave kernel
 }
@@ -651,13 +656,14 @@ def test_gpu_gls_degenerate_zero_pivot_column(monkeypatch, kind):
     assert plans["no_cube_kernel"]["hex8"] == 0 and plans["no_cube_kernel"]["mfw_small"] >= d["hex8"]
     assert plans["no_general_kind"]["mfw_general"] == 0 and plans["no_general_kind"]["mfx"] == 0
     assert plans["wide_for_two_coloured"]["mfx"] >= d["mfw_large"] + d["mfx"]
+    assert plans["no_boundary_in_wide"]["mfx_boundary"] == 0
     small = ("small4", "small8", "small12")
     assert sum(d[k] for k in small) > 0 and all(plans["no_small_kernel"][k] == 0 for k in small)
     assert (d["quad4"] > 0 or kind == "tet") and plans["no_quad_kernel"]["quad4"] == 0   # (wedge meshes have quad nodes too: their lateral faces)
     assert sum(plans["no_quad_kernel"][k] for k in small) == sum(d[k] for k in small) + d["quad4"]
     assert sum(plans["small_where_it_fits"][k] for k in small) >= sum(d[k] for k in small) + (d["hex8"] if kind == "hex" else 0)
     for route in ("block_only", "global_scratch"):
-        assert all(plans[route][k] == 0 for k in ("hex8", "mfw_large", "mfw_small", "mfw_general", "mfx", "quad4") + small), route
+        assert all(plans[route][k] == 0 for k in ("hex8", "mfw_large", "mfw_small", "mfw_general", "mfx", "mfx_boundary", "quad4") + small), route
     assert all(sum(p.values()) == I.grid.n_points for p in plans.values())
 
 
