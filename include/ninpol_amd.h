@@ -197,9 +197,11 @@ const char *nin_kernel_name(int method);
  * (at most 4 / 8 / 12 cells; in practice the boundary nodes that are computed), counts[12]: the two-lanes-per-node kernel for
  * the nodes inside a boundary face of a hexahedron mesh, counts[13..17]: the wide one-wavefront multifrontal kernel (interior nodes
  * of unstructured meshes: up to 16 fronts + 21 dense cells) by size class of its dense problem -- at most 96 x 40, 112 x 44,
- * 128 x 52, 144 x 60, 160 x 64 (rows x columns), counts[18]: its list of BOUNDARY nodes (computed only when flagged Neumann).  (Diagnostics and tests: the reference has one code path, gls.pyx:138-197,
+ * 128 x 52, 144 x 60, 160 x 64 (rows x columns), counts[18]: its list of BOUNDARY nodes (computed only when flagged Neumann),
+ * counts[19]: the multifrontal kernel whose dense problem lives in global-memory tiles (interior nodes beyond the wide kernel: up to 32 fronts +
+ * 40 dense cells, 256 x 121).  (Diagnostics and tests: the reference has one code path, gls.pyx:138-197,
  * for every node.) */
-int nin_gls_plan(const nin_grid *g, int64_t counts[19]);
+int nin_gls_plan(const nin_grid *g, int64_t counts[20]);
 
 /* Measurement: the FP64 flops one GLS launch performs, kernel by kernel of the launch plan (numbered as in
  * nin_gls_plan): alg[k] = ALGORITHMIC flops of the formulation kernel k runs on its nodes (fronts + dense rest for the
@@ -207,7 +209,7 @@ int nin_gls_plan(const nin_grid *g, int64_t counts[19]);
  * one-wavefront block / global-scratch kernels), ref[k] = the reference's dense dgels on the same nodes (gls.pyx:420-474),
  * computed[k] = the nodes that are computed at all (Dirichlet boundary nodes and nodes outside the parity set get the zero row).
  * Needs nin_fields_set (the Neumann flags decide which boundary nodes are computed). */
-int nin_gls_plan_flops(nin_grid *g, double alg[19], double ref[19], int64_t computed[19]);
+int nin_gls_plan_flops(nin_grid *g, double alg[20], double ref[20], int64_t computed[20]);
 
 /* ---- multi-GPU: the all-gather of the path as direct peer-to-peer writes ------------------------------------------
  * Replaces nothing in the reference (it is single-process); it is the exchange step north_star adds -- "a single allgatherv to

@@ -31,6 +31,7 @@ UNITS = [
     ("kernels_gls_hex8mf.hip", "hipcc", ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]),
     ("kernels_gls_mfw.hip", "hipcc", []),
     ("kernels_gls_mfx.hip", "hipcc", []),
+    ("kernels_gls_mfg.hip", "hipcc", []),
     ("kernels_gls_quad4.hip", "hipcc", []),
     ("kernels_csr.hip", "hipcc", []),
     # device-side grid build: no contraction, like grid_host.cpp (float32 normals must match the reference)

@@ -18,6 +18,7 @@
 #include "grid_host.hpp"
 #include "launch.hpp"
 #include "mfw_desc.hpp"
+#include "mfg_desc.hpp"
 #include "mfx_desc.hpp"
 
 using namespace nin;
@@ -477,13 +478,14 @@ int nin_grid_to_device(nin_grid *g, int device) {
     // ---- GLS launch plan: bin nodes by the size of their least-squares system (classified on the device) ----
     g->node_class.assign((size_t)P, 0);
     std::vector<std::vector<int32_t>> lists(kGlsClasses);
-    std::vector<int32_t> hex8_list, mfw_list[3], small_list[3], quad4_list, mfx_list[DeviceGrid::kMfxLists];
+    std::vector<int32_t> hex8_list, mfw_list[3], small_list[3], quad4_list, mfx_list[DeviceGrid::kMfxLists], mfg_list;
     // debugging switches: keep nodes away from the hex8 kernel (bit 0) / the one-wavefront multifrontal kernel (bit 1)
     const int use_group = (getenv("NIN_GLS_NO_GROUP") == nullptr ? 1 : 0) | (getenv("NIN_GLS_NO_MFW") == nullptr ? 2 : 0) |
                           (getenv("NIN_GLS_NO_MFW_GENERAL") == nullptr ? 4 : 0) |   // (bit 2: the multifrontal kernel's general kind)
                           (getenv("NIN_GLS_NO_SMALL") == nullptr ? 8 : 0) |         // (bit 3: the one-wavefront dense kernel for small nodes)
                           (getenv("NIN_GLS_NO_QUAD4") == nullptr ? 16 : 0) |        // (bit 4: the two-lanes-per-node kernel for quad nodes)
                           (getenv("NIN_GLS_NO_MFX") == nullptr ? 32 : 0) |          // (bit 5: the wide multifrontal kernel: unstructured meshes)
+                          (getenv("NIN_GLS_NO_MFG") == nullptr ? 256 : 0) |          // (bit 8: the multifrontal kernel on global-memory tiles: nodes beyond the wide kernel)
                           (getenv("NIN_GLS_MFX_NO_BOUNDARY") != nullptr ? 128 : 0) | // (bit 7: ... leaves the boundary nodes to the block kernel: round 3's route)
                           (getenv("NIN_GLS_MFW_GENERAL") == nullptr ? 64 : 0);      // (bit 6: ... takes the general kind's nodes too -- the default
                                                                                     //  since its dense phase runs straight-line per size class: 37 against
@@ -515,6 +517,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         else if (c == 248) quad4_list.push_back((int32_t)p);
         else if (c >= 243 && c <= 247) mfx_list[c - 243].push_back((int32_t)p);
         else if (c == 242) mfx_list[5].push_back((int32_t)p);
+        else if (c == 241) mfg_list.push_back((int32_t)p);
         else lists[c].push_back((int32_t)p);
     }
     for (int c = 0; c < kGlsClasses; ++c) {
@@ -580,6 +583,18 @@ int nin_grid_to_device(nin_grid *g, int device) {
             if (launch_mfx_desc(d.v, d.mfx[i].nodes, d.mfx[i].count, d.mfx_desc[i], nullptr)) return fail(NIN_EHIP, "mfx descriptor kernel");
         }
     }
+    {
+        d.mfg.count = (int32_t)mfg_list.size();
+        const int32_t *lp = nullptr;
+        if (d.mfg.count && (rc = dev_upload(d, &lp, mfg_list))) return rc;
+        d.mfg.nodes = const_cast<int32_t *>(lp);
+        if (d.mfg.count) {   // descriptors, kMfgDescWords (124) words per list entry, and one slot of tiles per resident wavefront
+            if ((rc = dev_alloc(d, &d.mfg_desc, (size_t)d.mfg.count * kMfgDescWords))) return rc;
+            if (launch_mfg_desc(d.v, d.mfg.nodes, d.mfg.count, d.mfg_desc, nullptr)) return fail(NIN_EHIP, "mfg descriptor kernel");
+            d.mfg_slots = std::min<int32_t>(d.mfg.count, kMfgResidentWaves);
+            if ((rc = dev_alloc(d, &d.mfg_tiles, (size_t)d.mfg_slots * kMfgSlotDoubles))) return rc;
+        }
+    }
     for (int i = 0; i < 3; ++i) {
         d.small[i].count = (int32_t)small_list[i].size();
         const int32_t *lp = nullptr;
@@ -617,6 +632,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         for (int i = 0; i < 3; ++i) cut(kGlsClasses + 4 + i, small_list[i]);
         cut(kGlsClasses + 7, quad4_list);
         for (int i = 0; i < DeviceGrid::kMfxLists; ++i) cut(kGlsClasses + 8 + i, mfx_list[i]);
+        cut(kGlsClasses + 8 + DeviceGrid::kMfxLists, mfg_list);
         const char *mn = getenv("NIN_E2E_MIN_NODES");                                // (tests: the pipeline on small meshes too)
         d.chunkable = P >= (mn ? atoll(mn) : 64 * 1024) && P >= 64 * K && getenv("NIN_E2E_NO_PIPELINE") == nullptr;   // small meshes: one piece
     }
@@ -724,6 +740,8 @@ static int launch_gls_but_cube(DeviceGrid &d, int add_neumann, double *out, doub
     if (!rc && on(12)) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, out, nws, stream);
     for (int i = 0; i < DeviceGrid::kMfxLists && !rc; ++i)   // (work counters: ints 8 .. 13)
         if (on(13 + i)) rc = launch_gls_mfx(d.v, d.mfx[i].nodes, d.mfx_desc[i], d.mfx[i].count, i, add_neumann, out, nws, d.gls_queue + 8 + i, stream);
+    if (!rc && on(19))   // (work counter: int 14)
+        rc = launch_gls_mfg(d.v, d.mfg.nodes, d.mfg_desc, d.mfg.count, add_neumann, out, nws, d.gls_queue + 14, d.mfg_tiles, d.mfg_slots, stream);
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         if ((c == kGlsClasses - 1 && d.side_pending) || !on(c)) continue;
         rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, out, nws, stream);
@@ -769,7 +787,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     HIP_TRY(hipMemsetAsync(dev_csr_data, 0, (size_t)d.nnz_e * 8, stream));
     HIP_TRY(hipMemsetAsync(dev_neumann_ws, 0, (size_t)P * 8, stream));
     if (n_targets == 0) return NIN_OK;
-    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 8 + DeviceGrid::kMfxLists : 1);
+    std::vector<std::vector<int32_t>> lists(method == NIN_METHOD_GLS ? kGlsClasses + 8 + DeviceGrid::kMfxLists + 1 : 1);
     for (int64_t i = 0; i < n_targets; ++i) {
         int c = method == NIN_METHOD_GLS ? g->node_class[targets[i]] : 0;
         if (c == 255) c = kGlsClasses;   // the hex8 kernel's class
@@ -778,6 +796,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else if (c == 248) c = kGlsClasses + 7;                           // the quad-node kernel
         else if (c >= 243 && c <= 247) c = kGlsClasses + 8 + (c - 243);   // the wide multifrontal kernel, by size class
         else if (c == 242) c = kGlsClasses + 8 + 5;                       // ... its boundary nodes
+        else if (c == 241) c = kGlsClasses + 8 + DeviceGrid::kMfxLists;   // the multifrontal kernel on global-memory tiles
         lists[c].push_back((int32_t)targets[i]);
     }
     // one device buffer for all class lists, filled before the first launch: a per-class allocate / copy / free
@@ -797,11 +816,13 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     size_t n_mfx = 0;                                                                      // + kMfxDescWords per node of the wide multifrontal kernel (its lists are adjacent)
     if (method == NIN_METHOD_GLS)
         for (int i = 0; i < DeviceGrid::kMfxLists; ++i) n_mfx += lists[kGlsClasses + 8 + i].size();
-    HIP_TRY(hipMalloc((void **)&dl0, (flat.size() + 4 * n_hex8 + kMfwDescWords * n_mfw + 2 * n_quad4 + kMfxDescWords * n_mfx) * 4));
+    const size_t n_mfg = method == NIN_METHOD_GLS ? lists[kGlsClasses + 8 + DeviceGrid::kMfxLists].size() : 0;   // + kMfgDescWords per node of kernels_gls_mfg.hip
+    HIP_TRY(hipMalloc((void **)&dl0, (flat.size() + 4 * n_hex8 + kMfwDescWords * n_mfw + 2 * n_quad4 + kMfxDescWords * n_mfx + kMfgDescWords * n_mfg) * 4));
     int32_t *ddesc = dl0 + flat.size();
     uint32_t *dmfw = reinterpret_cast<uint32_t *>(ddesc + 4 * n_hex8);
     int32_t *dquad = reinterpret_cast<int32_t *>(dmfw + kMfwDescWords * n_mfw);
     uint32_t *dmfx = reinterpret_cast<uint32_t *>(dquad + 2 * n_quad4);
+    uint32_t *dmfg = dmfx + kMfxDescWords * n_mfx;
     const hipError_t cp = hipMemcpy(dl0, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
     if (cp != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemcpy: %s", hipGetErrorString(cp)); }
     if (n_hex8 && launch_hex8_desc(d.v, dl0 + first[kGlsClasses], (int32_t)n_hex8, ddesc, stream)) {
@@ -820,6 +841,10 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         (void)hipFree(dl0);
         return fail(NIN_EHIP, "mfx descriptor kernel");
     }
+    if (n_mfg && launch_mfg_desc(d.v, dl0 + first[kGlsClasses + 8 + DeviceGrid::kMfxLists], (int32_t)n_mfg, dmfg, stream)) {
+        (void)hipFree(dl0);
+        return fail(NIN_EHIP, "mfg descriptor kernel");
+    }
     if (method == NIN_METHOD_GLS) {
         const hipError_t qe = hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream);
         if (qe != hipSuccess) { (void)hipFree(dl0); return fail(NIN_EHIP, "hipMemsetAsync: %s", hipGetErrorString(qe)); }
@@ -831,6 +856,8 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_hex8(d, dl, ddesc, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
+        else if ((int)c == kGlsClasses + 8 + DeviceGrid::kMfxLists)
+            rc = launch_gls_mfg(d.v, dl, dmfg, cnt, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue + 14, d.mfg_tiles, d.mfg_slots, stream);
         else if ((int)c >= kGlsClasses + 8)
             rc = launch_gls_mfx(d.v, dl, dmfx + kMfxDescWords * (first[c] - first[kGlsClasses + 8]), cnt, (int)c - kGlsClasses - 8, add_neumann, dev_csr_data,
                                 dev_neumann_ws, d.gls_queue + 8 + ((int)c - kGlsClasses - 8), stream);
@@ -993,6 +1020,11 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
     for (int i = 0; i < DeviceGrid::kMfxLists && !rc; ++i) {
         const int32_t b = d.chunk_off[kGlsClasses + 8 + i][k], n = d.chunk_off[kGlsClasses + 8 + i][k + 1] - b;
         if (n > 0) rc = launch_gls_mfx(d.v, d.mfx[i].nodes + b, d.mfx_desc[i] + (size_t)kMfxDescWords * b, n, i, 1, out, nws, d.gls_queue + 8 + i, stream);
+    }
+    if (!rc) {
+        constexpr int li = kGlsClasses + 8 + DeviceGrid::kMfxLists;
+        const int32_t b = d.chunk_off[li][k], n = d.chunk_off[li][k + 1] - b;
+        if (n > 0) rc = launch_gls_mfg(d.v, d.mfg.nodes + b, d.mfg_desc + (size_t)kMfgDescWords * b, n, 1, out, nws, d.gls_queue + 14, d.mfg_tiles, d.mfg_slots, stream);
     }
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         const int32_t b = d.chunk_off[c][k], n = d.chunk_off[c][k + 1] - b;
@@ -1270,7 +1302,7 @@ double dense_flops(int64_t ne, int64_t n_if, int64_t n_nb) {
 double dgels_flops(double m, double n, double nrhs) { return 2 * m * n * n - 2 * n * n * n / 3 + nrhs * (4 * m * n - 2 * n * n) + nrhs * n * n; }
 }  // namespace
 
-int nin_gls_plan_flops(nin_grid *g, double alg[19], double ref[19], int64_t computed[19]) {
+int nin_gls_plan_flops(nin_grid *g, double alg[20], double ref[20], int64_t computed[20]) {
     if (!g || !alg || !ref || !computed) return fail(NIN_EINVAL, "NULL argument");
     DeviceGrid &d = g->d;
     HostGrid &h = g->h;
@@ -1278,7 +1310,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[19], double ref[19], int64_t comp
     if (!d.fields_set || !d.flag_staging) return fail(NIN_ESTATE, "nin_fields_set has not been called (the Neumann flags decide which boundary nodes are computed)");
     if (h.ensure(A_ESUP_PTR | A_ESUP | A_FSUP_PTR | A_FSUP | A_ESUF)) return fail(NIN_EHIP, "mirroring the connectivity failed");
     HIP_TRY(hipSetDevice(d.device));
-    for (int k = 0; k < 19; ++k) { alg[k] = ref[k] = 0.0; computed[k] = 0; }
+    for (int k = 0; k < 20; ++k) { alg[k] = ref[k] = 0.0; computed[k] = 0; }
     const int64_t P = h.n_points;
     // (F, D, free faces) of the nodes of the multifrontal kernels: from their descriptors
     std::vector<uint32_t> fdq((size_t)P, 0u);
@@ -1295,9 +1327,10 @@ int nin_gls_plan_flops(nin_grid *g, double alg[19], double ref[19], int64_t comp
         if (read_desc(d.mfw[i].nodes, d.mfw_desc[i], d.mfw[i].count, kMfwDescWords, 24)) return fail(NIN_EHIP, "reading the descriptors back failed");
     for (int i = 0; i < DeviceGrid::kMfxLists; ++i)
         if (read_desc(d.mfx[i].nodes, d.mfx_desc[i], d.mfx[i].count, kMfxDescWords, 0)) return fail(NIN_EHIP, "reading the descriptors back failed");
+    if (read_desc(d.mfg.nodes, d.mfg_desc, d.mfg.count, kMfgDescWords, 0)) return fail(NIN_EHIP, "reading the descriptors back failed");
     for (int64_t p = 0; p < P; ++p) {
         const int c = g->node_class[p];
-        const int k = c == 255 ? 5 : (c >= 252 && c <= 254) ? 6 + (254 - c) : (c >= 249 && c <= 251) ? 9 + (c - 249) : c == 248 ? 12 : (c >= 243 && c <= 247) ? 13 + (c - 243) : c == 242 ? 18 : c;
+        const int k = c == 255 ? 5 : (c >= 252 && c <= 254) ? 6 + (254 - c) : (c >= 249 && c <= 251) ? 9 + (c - 249) : c == 248 ? 12 : (c >= 243 && c <= 247) ? 13 + (c - 243) : c == 242 ? 18 : c == 241 ? 19 : c;
         const int fl = d.flag_staging[p];
         if ((fl & 1) && !(fl & 2)) continue;                   // a Dirichlet boundary node: the zero row, nothing computed (gls.pyx:165-166)
         const int64_t eb = h.esup_ptr[p], ne = h.esup_ptr[p + 1] - eb, fb = h.fsup_ptr[p], nf = h.fsup_ptr[p + 1] - fb;
@@ -1355,7 +1388,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[19], double ref[19], int64_t comp
     return NIN_OK;
 }
 
-int nin_gls_plan(const nin_grid *g, int64_t counts[19]) {
+int nin_gls_plan(const nin_grid *g, int64_t counts[20]) {
     if (!g || !counts) return fail(NIN_EINVAL, "NULL argument");
     if (g->d.device < 0 || g->d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
     for (int c = 0; c < kGlsClasses; ++c) counts[c] = g->d.gls[c].count;
@@ -1366,6 +1399,7 @@ int nin_gls_plan(const nin_grid *g, int64_t counts[19]) {
     for (int i = 0; i < 3; ++i) counts[9 + i] = g->d.small[i].count;
     counts[12] = g->d.quad4.count;
     for (int i = 0; i < DeviceGrid::kMfxLists; ++i) counts[13 + i] = g->d.mfx[i].count;
+    counts[19] = g->d.mfg.count;
     return NIN_OK;
 }
 

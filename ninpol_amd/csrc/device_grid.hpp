@@ -88,6 +88,12 @@ struct DeviceGrid {
     static constexpr int kMfxLists = 6;   // (the sixth: boundary nodes, kernels_gls_mfx.hip's BND instantiation)
     GlsClass mfx[kMfxLists];
     uint32_t *mfx_desc[kMfxLists] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [kMfxDescWords * mfx[c].count] descriptor words
+    // kernels_gls_mfg.hip (mfg_desc.hpp): interior nodes beyond the wide kernel's registers (up to 32 fronts + 40 dense cells): the tiles
+    // of the dense problem in a global-memory slot per resident wavefront
+    GlsClass mfg;
+    uint32_t *mfg_desc = nullptr;   // [kMfgDescWords * mfg.count] descriptor words
+    double *mfg_tiles = nullptr;    // [mfg_slots][kMfgSlotDoubles]
+    int32_t mfg_slots = 0;
     const int32_t *noncube_nodes = nullptr;   // every node the cube-node kernel does not take (the fused apply's list kernel)
     int32_t noncube_count = 0;
     bool noncube_nodes_ready = false;
@@ -118,7 +124,7 @@ struct DeviceGrid {
     // (lists 0 .. kGlsClasses - 1: the block kernel's classes, then the cube-node kernel, the three mfw kinds, the three small kinds, the quad nodes, the wide multifrontal kernel's five size classes)
     static constexpr int kE2eChunks = 4;
     int32_t chunk_node[kE2eChunks + 1] = {0, 0, 0, 0, 0};
-    int32_t chunk_off[kGlsClasses + 8 + kMfxLists][kE2eChunks + 1] = {};
+    int32_t chunk_off[kGlsClasses + 8 + kMfxLists + 1][kE2eChunks + 1] = {};   // (the last: kernels_gls_mfg.hip's list)
     bool chunkable = false;
     bool gls_too_large = false;     // some node's system has more rows than the scratch kernel handles (1024)
 };

@@ -29,6 +29,7 @@
 #include "hex8_desc.hpp"
 #include "quad4_desc.hpp"
 #include "mfw_desc.hpp"
+#include "mfg_desc.hpp"
 #include "mfx_desc.hpp"
 #include "launch.hpp"
 
@@ -589,6 +590,12 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
         const int k = mfx_descriptor(g, (int32_t)p, w);   // 1 + the size class of its dense problem
         if (k > 0 && nbf == 0) { node_class[p] = (uint8_t)(243 + k - 1); return; }
         if (k > 0 && k <= 2) { node_class[p] = 242; return; }   // a boundary node that fits 7 x 11 tiles: the boundary instantiation's list
+    }
+    // interior nodes beyond the wide kernel's 16 fronts + 21 dense cells (a random point cloud's Delaunay mesh: 6 % of its nodes): the
+    // dense problem in global-memory tiles (kernels_gls_mfg.hip, mfg_desc.hpp; bit 8: NIN_GLS_NO_MFG clears it)
+    if ((use_group & 256) && (use_group & 32) && !force_global && nbf == 0 && ne > 12 && ne <= kMfgMaxCells) {
+        uint32_t w[kMfgDescWords];
+        if (mfg_descriptor(g, (int32_t)p, w)) { node_class[p] = 241; return; }
     }
     // nodes inside a boundary face of a hexahedron mesh: two lanes per node (kernels_gls_quad4.hip)
     if ((use_group & 16) && !force_global && ne == 4 && nf == 8 && nbf == 4 && g.dim == 3) {

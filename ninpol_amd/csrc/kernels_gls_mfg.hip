@@ -1,0 +1,420 @@
+// kernels_gls_mfg.hip -- GLS weights of interior nodes with MORE cells than a wavefront's registers hold (mfg_desc.hpp: up to 32 fronts +
+// 40 dense cells; a Poisson-Delaunay cloud has 6 % of its nodes beyond kernels_gls_mfx.hip's 16 + 21), gfx950: one wavefront per node,
+// the dense problem -- up to 256 x 121 -- as 16-row x 4-column tiles in a GLOBAL-memory slot of the wavefront.
+//
+// What these nodes had before: the block kernel while the FULL m x n system fits a CU's LDS (up to ~36 cells), then the wave kernel of
+// kernels_gls.hip on a global-memory copy of the full system: one Householder reflector per sweep of the whole trailing matrix --
+// ~60 MB of traffic and ~7 ms a node; 1 770 such nodes of a 186 k-cell random cloud took 13.7 of its 13.8 ms.  Here
+//   * the fronts are eliminated first, in the lanes (kernels_gls_mfx.hip's phase 1, in passes of 16 fronts): (7 F + D + 3 free) x
+//     (3 D + 1) is left -- a quarter of the entries;
+//   * the dense problem is factored in PANELS OF FOUR reflectors (compact WY, mfw_strips.hpp's strip form: the FP64 matrix unit as the
+//     cross-lane adder), so a trailing tile is read and written once per panel, not once per reflector: ~3 MB a node, every access a
+//     whole 512-byte tile (lane = element);
+//   * nothing but the panel block and one column block is in registers at a time: ~130 registers, two wavefronts per SIMD, and the loops
+//     over tiles and column blocks are ordinary run-time loops (a lane only ever touches its own element of a tile, so the tiles need no
+//     synchronisation between the panels);
+//   * R stays where the factorisation leaves it (the tiles are not shifted) and R y = Q^T c is solved block column by block column
+//     straight from the tiles.
+// Same mathematics as dgels on the reference's matrix (gls.pyx:252-474): a Householder QR under a column / row order that exposes the zeros.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "device_grid.hpp"
+#include "gls_device_math.hpp"
+#include "launch.hpp"
+#include "mfg_desc.hpp"
+#include "mfw_strips.hpp"
+
+namespace nin {
+
+namespace {
+
+using namespace glsmath;
+using namespace mfwstrips;
+
+constexpr int GQ = kMfgRowTiles, GCB = kMfgColBlocks;
+constexpr int G_Y = 0, G_W = 128, G_DESC = G_W + 64, G_PER_WAVE = G_DESC + kMfgDescWords / 2;   // LDS (doubles): y | weights | descriptor
+
+// element (row, col) of the dense problem in the wavefront's slot: tile (row >> 4, col >> 2) at ((col >> 2) * 16 + (row >> 4)) * 64 -- the
+// tiles of a column block lie behind one another --, lane 16 (row & 3) + 4 ((row >> 2) & 3) + (col & 3) of the tile
+__device__ __forceinline__ int tile_index(int row, int col) {
+    return ((((col >> 2) * GQ) + (row >> 4)) << 6) + 16 * (row & 3) + 4 * ((row >> 2) & 3) + (col & 3);
+}
+
+__device__ __forceinline__ void wave_global_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One step K of a panel whose pivot rows are quad bp of its first tile: P[k] = the panel block of tile q0 + k, k < cnt.
+// As strip_panel_step (mfw_strips.hpp), the tile loops behind wave-uniform guards.
+template <int K>
+__device__ __forceinline__ void gpanel_step(double (&P)[GQ], double (&xm)[GQ], double (&vp)[4], double (&Tr)[4], int cnt, int bp, int si, int sb,
+                                            int sj) {
+    const bool in_piv_quad = sb == bp;
+    const bool is_piv = in_piv_quad && si == K;
+    const bool below0 = sb > bp || (in_piv_quad && si > K);
+    xm[0] = below0 ? quad_pick<K>(P[0]) : 0.0;
+    double acc = xm[0] * P[0];
+#pragma unroll
+    for (int k = 1; k < GQ; ++k) {
+        if (k < cnt) {
+            xm[k] = quad_pick<K>(P[k]);
+            acc = fma(xm[k], P[k], acc);
+        }
+    }
+    const double ap = __shfl(P[0], 16 * K + 4 * bp + sj);        // the pivot row's entry of column j
+    const double d = sum_rows(sum_quads(acc));
+    const House h = house_unguarded(quad_pick<K>(ap), quad_pick<K>(d));
+    const double e = fma(h.vp, ap, d);
+    const double w = sj > K ? -(h.g * e) : 0.0;
+    vp[K] = h.vp;
+    {
+        double t = 0.0;
+        if (K >= 1) t = Tr[0] * quad_pick<0>(e);
+        if (K >= 2) t = fma(Tr[1], quad_pick<1>(e), t);
+        if (K >= 3) t = fma(Tr[2], quad_pick<2>(e), t);
+        Tr[K] = si == K ? h.g : -(h.g * t);
+    }
+    {
+        const double x = fma(w, is_piv ? h.vp : xm[0], P[0]);
+        P[0] = (is_piv && sj == K) ? h.beta : x;
+    }
+#pragma unroll
+    for (int k = 1; k < GQ; ++k) {
+        if (k < cnt) P[k] = fma(w, xm[k], P[k]);
+    }
+}
+
+// Factor the nrows x (nc + 1) problem held in the slot (c at column nc), solve R y = Q^T c: y -> yb (LDS), returns r . r.
+__device__ __forceinline__ double mfg_factor_solve(double *__restrict__ slot, int nc, int nrows, int lane, double *yb) {
+    const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3, rowbase = 4 * sb + si;
+    const double eye = si == sj ? 1.0 : 0.0;
+    const int n_panels = (nc + 3) >> 2, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
+    double *const mine = slot + lane;
+    for (int p = 0; p < n_panels; ++p) {
+        const int q0 = p >> 2, bp = p & 3, steps = nc - 4 * p < 4 ? nc - 4 * p : 4, cnt = nq - q0;
+        double P[GQ], xm[GQ], vp[4] = {0.0, 0.0, 0.0, 0.0}, Tr[4] = {0.0, 0.0, 0.0, 0.0};
+        double *const pb = mine + ((p * GQ + q0) << 6);
+#pragma unroll
+        for (int k = 0; k < GQ; ++k) {
+            P[k] = 0.0;
+            if (k < cnt) P[k] = pb[k << 6];
+        }
+        gpanel_step<0>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
+        if (steps > 1) gpanel_step<1>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
+        if (steps > 2) gpanel_step<2>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
+        if (steps > 3) gpanel_step<3>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
+        pb[0] = P[0];                                            // the panel's rows of R (and, in a last panel with c in its block, Q^T c)
+        if (steps < 4) {                                         // ... whose rows below the pivots count in r . r
+#pragma unroll
+            for (int k = 1; k < GQ; ++k)
+                if (k < cnt) pb[k << 6] = P[k];
+        }
+        if (steps == 4 && p + 1 < ncb) {
+            {
+                // P becomes V: below the pivots the panel's columns are the reflectors; in the pivot quad the diagonal takes v's pivot
+                // entries, everything above it (R) and every row above the quad (earlier panels' rows of R) is zero
+                const double vdiag = sj == 0 ? vp[0] : sj == 1 ? vp[1] : sj == 2 ? vp[2] : vp[3];
+                double v0 = P[0];
+                v0 = (sb == bp && si == sj) ? vdiag : v0;
+                v0 = (sb < bp || (sb == bp && si < sj)) ? 0.0 : v0;
+                P[0] = v0;
+            }
+            const double Ts = -(sj == 0 ? Tr[0] : sj == 1 ? Tr[1] : sj == 2 ? Tr[2] : Tr[3]);
+            double VT[GQ];                                       // V^T per quad: the A operand of C -= V W'
+#pragma unroll
+            for (int k = 0; k < GQ; ++k)
+                if (k < cnt) VT[k] = mfma4(P[k], eye, 0.0);
+            for (int cb = p + 1; cb < ncb; ++cb) {
+                double *const cp = mine + ((cb * GQ + q0) << 6);
+                double Ct[GQ], W = 0.0;
+#pragma unroll
+                for (int k = 0; k < GQ; ++k)
+                    if (k < cnt) Ct[k] = cp[k << 6];
+#pragma unroll
+                for (int k = 0; k < GQ; ++k)
+                    if (k < cnt) W = mfma4(P[k], Ct[k], W);
+                W = mfma4(Ts, sum_quads(W), 0.0);                // -(T^T V^T C), the same in every quad
+#pragma unroll
+                for (int k = 0; k < GQ; ++k)
+                    if (k < cnt) cp[k << 6] = mfma4(VT[k], W, Ct[k]);
+            }
+        }
+    }
+    // c sits in block nc >> 2, column nc & 3
+    const int cbc = nc >> 2, jc = nc & 3;
+    double *const cc = mine + ((cbc * GQ) << 6);
+    double rr = 0.0;
+    {
+        double t = 0.0;
+        for (int q = 0; q < nq; ++q) {
+            const double x = cc[q << 6];
+            const double xr = (16 * q + rowbase >= nc && sj == jc) ? x : 0.0;
+            t = fma(xr, xr, t);
+        }
+        rr = wave_allsum(t);
+    }
+    // ---- R y = (Q^T c)(0 : nc), block column by block column from the last: b[k] = this lane's ROW of the right-hand side in tile k ----
+    constexpr int BQ = (kMfgMaxDense * 3 + 15) / 16;           // row tiles that hold pivot rows
+    double b[BQ];
+#pragma unroll
+    for (int k = 0; k < BQ; ++k) {
+        b[k] = 0.0;
+        if (16 * k < nc) b[k] = __shfl(cc[k << 6], (lane & ~3) | jc);
+    }
+    for (int cb = (nc - 1) >> 2; cb >= 0; --cb) {
+        const int q = cb >> 2, quad = cb & 3, live = nc - 4 * cb < 4 ? nc - 4 * cb : 4;   // (a last block shares its columns with c)
+        double *const cp = mine + ((cb * GQ) << 6);
+        const double Dt = cp[q << 6];
+        double bq = 0.0;
+#pragma unroll
+        for (int k = 0; k < BQ; ++k) bq = k == q ? b[k] : bq;
+        double y[4];
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            double s = __shfl(bq, 16 * i + 4 * quad);
+#pragma unroll
+            for (int j = 3; j > i; --j) s = fma(-__shfl(Dt, 16 * i + 4 * quad + j), y[j], s);
+            const double yi = s * fast_rcp(__shfl(Dt, 16 * i + 4 * quad + i));
+            y[i] = i < live ? yi : 0.0;
+        }
+        if (lane < live) yb[4 * cb + lane] = lane == 0 ? y[0] : lane == 1 ? y[1] : lane == 2 ? y[2] : y[3];
+        const double ysel = sj == 0 ? y[0] : sj == 1 ? y[1] : sj == 2 ? y[2] : y[3];
+#pragma unroll
+        for (int k = 0; k < BQ; ++k) {
+            if (k <= q) {                                        // the rows above the block: b -= R(:, block) y
+                const double tv = k == q ? Dt : cp[k << 6];
+                double part = tv * ysel;
+                part += dpp_mov<0xB1>(part);                     // sum over the quad's four columns
+                part += dpp_mov<0x4E>(part);
+                const bool above = k < q || sb < quad;
+                b[k] = above ? b[k] - part : b[k];
+            }
+        }
+    }
+    return rr;
+}
+
+__global__ __launch_bounds__(64, 2) void nin_gls_mfg_kernel(GridView g, const int32_t *__restrict__ nodes, const uint32_t *__restrict__ desc,
+                                                           int32_t count, int add_neumann, double *__restrict__ out, double *__restrict__ nws,
+                                                           int32_t *__restrict__ queue, double *__restrict__ tiles) {
+    __shared__ double Lm[G_PER_WAVE];
+    const int lane = threadIdx.x;
+    double *const yb = Lm + G_Y, *const wbuf = Lm + G_W;
+    uint32_t *const dl = reinterpret_cast<uint32_t *>(Lm + G_DESC);
+    const uint8_t *const slotpos = reinterpret_cast<const uint8_t *>(dl + kMfgSlotTable);
+    double *const slot = tiles + (size_t)blockIdx.x * kMfgSlotDoubles;
+
+    auto ticket = [&]() -> int32_t {
+        int32_t v = 0;
+        if (lane == 0) v = atomicAdd(queue, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    for (int32_t idx = ticket(); idx < count; idx = ticket()) {
+        const int32_t p = __builtin_amdgcn_readfirstlane(nodes ? nodes[idx] : idx);
+        const uint32_t *dw = desc + (size_t)kMfgDescWords * idx;
+        for (int k = lane; k < kMfgDescWords; k += 64) dl[k] = dw[k];
+        const uint32_t fd = (uint32_t)__builtin_amdgcn_readfirstlane((int)dw[0]);
+        const int F = fd & 255, D = (fd >> 8) & 255, nfree = (fd >> 16) & 255, ne = F + D;
+        const uint32_t eb = (uint32_t)__builtin_amdgcn_readfirstlane(g.esup_ptr[p]);
+        const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane(g.fsup_ptr[p]);
+        const bool is_neu = (__builtin_amdgcn_readfirstlane((int)g.flags[p]) & 2) != 0;
+        const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1], xv2 = g.coords[3 * (size_t)p + 2];
+        const int nc = 3 * D, nrows = 7 * F + D + 3 * nfree, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
+        // the tiles of this node: zero (a lane clears its own element of every tile)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int q = 0; q < nq; ++q) slot[((cb * GQ + q) << 6) + lane] = 0.0;
+        wave_lds_sync();
+        wave_global_sync();
+        // ---- phase 1: the fronts in passes of 16, FOUR lanes per front (lane 4 f + j: c for j = 0, the columns of neighbour j - 1 otherwise);
+        //      the 7 fill rows of a front go straight to their elements of the tiles ------------------------------------------------
+        const int fq = lane >> 2, jq = lane & 3, my = jq > 0 ? jq - 1 : 0;
+        double u[2][3];
+        uint32_t pe_[2], slot_[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            u[pass][0] = u[pass][1] = u[pass][2] = 0.0;
+            pe_[pass] = slot_[pass] = 0u;
+            if (16 * pass < F) {                                 // (wave-uniform)
+                const int f = 16 * pass + fq;
+                const uint32_t wa = dl[kMfgW0 + f], wb = dl[kMfgW1 + f];
+                const uint32_t pe = wa & 63u, myslot = (wb >> (6 * my)) & 63u;
+                pe_[pass] = pe;
+                slot_[pass] = myslot;
+                const uint32_t ce = (uint32_t)g.esup[eb + pe], cm = (uint32_t)g.esup[eb + slotpos[myslot]];
+                double P[10][3], B[10][3], de[3];
+                double Ke[9], Km[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { Ke[k] = g.perm[9 * (size_t)ce + k]; Km[k] = g.perm[9 * (size_t)cm + k]; }
+                const double dme = g.diff_mag[ce];
+                de[0] = g.centroids[3 * (size_t)ce + 0] - xv0;  // gls.pyx:269-277
+                de[1] = g.centroids[3 * (size_t)ce + 1] - xv1;
+                de[2] = g.centroids[3 * (size_t)ce + 2] - xv2;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { P[0][t] = de[t]; B[0][t] = (jq == 0 && t == 0) ? 1.0 : 0.0; }   // c = e_0 on entry
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    // B = [K N; T1; tau T2] (gls.pyx:293-321), row = [-B_a | +B_b] (gls.pyx:340-356)
+                    const uint32_t fc = (uint32_t)g.fsup[fb + ((wa >> (6 + 7 * i)) & 127u)];
+                    const uint32_t cn = (uint32_t)g.esup[eb + slotpos[(wb >> (6 * i)) & 63u]];
+                    const double N0 = (double)g.face_normal[3 * (size_t)fc + 0], N1 = (double)g.face_normal[3 * (size_t)fc + 1],
+                                 N2 = (double)g.face_normal[3 * (size_t)fc + 2];
+                    const double T0 = xv0 - g.face_center[3 * (size_t)fc + 0], T1 = xv1 - g.face_center[3 * (size_t)fc + 1],
+                                 T2 = xv2 - g.face_center[3 * (size_t)fc + 2];
+                    const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+                    const double dmn = g.diff_mag[cn];
+                    double eta = 0.0;
+                    eta = dme > eta ? dme : eta;
+                    eta = dmn > eta ? dmn : eta;
+                    const double tj = face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
+                    const double sg = ((wa >> (27 + i)) & 1u) ? -1.0 : 1.0;
+                    const bool mine_ = jq > 0 && my == i;
+                    const double s0[3] = {sg * T0, sg * T1, sg * T2}, s1[3] = {sg * (tj * U0), sg * (tj * U1), sg * (tj * U2)};
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        P[1 + 3 * i][t] = sg * (Ke[t * 3 + 0] * N0 + Ke[t * 3 + 1] * N1 + Ke[t * 3 + 2] * N2);
+                        P[2 + 3 * i][t] = s0[t];
+                        P[3 + 3 * i][t] = s1[t];
+                        const double nb = -sg * (Km[t * 3 + 0] * N0 + Km[t * 3 + 1] * N1 + Km[t * 3 + 2] * N2);
+                        B[1 + 3 * i][t] = mine_ ? nb : 0.0;
+                        B[2 + 3 * i][t] = mine_ ? -s0[t] : 0.0;
+                        B[3 + 3 * i][t] = mine_ ? -s1[t] : 0.0;
+                    }
+                }
+                double g3[3], z[3];
+                front_panel(P, de, g3, z);
+                __builtin_amdgcn_sched_barrier(0);
+                apply_panel<3, true, true, true, true>(P, g3, B);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) u[pass][t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));
+                if (f < F) {
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) {
+                        const int row = 7 * f + r;
+                        if (jq == 0) slot[tile_index(row, nc)] = B[3 + r][0];
+                        else {
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) slot[tile_index(row, 3 * (int)myslot + t)] = B[3 + r][t];
+                        }
+                    }
+                }
+            }
+        }
+        // the dense cells' rows: (x_K - x_v) on the cell's own columns, c = 1 (lane d = dense slot d)
+        const uint32_t po = slotpos[lane < kMfgMaxDense ? lane : 0];
+        double dod[3];
+        {
+            const uint32_t co = (uint32_t)g.esup[eb + po];
+            dod[0] = g.centroids[3 * (size_t)co + 0] - xv0;
+            dod[1] = g.centroids[3 * (size_t)co + 1] - xv1;
+            dod[2] = g.centroids[3 * (size_t)co + 2] - xv2;
+            if (lane < D) {
+                const int row = 7 * F + lane;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) slot[tile_index(row, 3 * lane + t)] = dod[t];
+                slot[tile_index(row, nc)] = 1.0;
+            }
+        }
+        if (lane < nfree) {
+            // a free face (both its cells dense): its three rows [-B_a | +B_b] (gls.pyx:293-356)
+            const uint32_t fw = dl[kMfgFree0 + lane];
+            const uint32_t fc = (uint32_t)g.fsup[fb + (fw & 127u)];
+            const int sa = (fw >> 7) & 63u, sbb = (fw >> 13) & 63u;
+            const uint32_t ca_ = (uint32_t)g.esup[eb + slotpos[sa]], cb_ = (uint32_t)g.esup[eb + slotpos[sbb]];
+            const double N0 = (double)g.face_normal[3 * (size_t)fc + 0], N1 = (double)g.face_normal[3 * (size_t)fc + 1],
+                         N2 = (double)g.face_normal[3 * (size_t)fc + 2];
+            const double T0 = xv0 - g.face_center[3 * (size_t)fc + 0], T1 = xv1 - g.face_center[3 * (size_t)fc + 1],
+                         T2 = xv2 - g.face_center[3 * (size_t)fc + 2];
+            const double U0 = N1 * T2 - N2 * T1, U1 = N2 * T0 - N0 * T2, U2 = N0 * T1 - N1 * T0;
+            const double da = g.diff_mag[ca_], db = g.diff_mag[cb_];
+            double eta = 0.0;
+            eta = da > eta ? da : eta;
+            eta = db > eta ? db : eta;
+            const double tj = face_tau(sqrt(U0 * U0 + U1 * U1 + U2 * U2), eta);
+            const double *Ka = g.perm + 9 * (size_t)ca_, *Kb = g.perm + 9 * (size_t)cb_;
+            const double Tv[3] = {T0, T1, T2}, Uv[3] = {tj * U0, tj * U1, tj * U2};
+            const int row = 7 * F + D + 3 * lane;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                slot[tile_index(row + 0, 3 * sa + t)] = -(Ka[t * 3 + 0] * N0 + Ka[t * 3 + 1] * N1 + Ka[t * 3 + 2] * N2);
+                slot[tile_index(row + 0, 3 * sbb + t)] = Kb[t * 3 + 0] * N0 + Kb[t * 3 + 1] * N1 + Kb[t * 3 + 2] * N2;
+                slot[tile_index(row + 1, 3 * sa + t)] = -Tv[t];
+                slot[tile_index(row + 1, 3 * sbb + t)] = Tv[t];
+                slot[tile_index(row + 2, 3 * sa + t)] = -Uv[t];
+                slot[tile_index(row + 2, 3 * sbb + t)] = Uv[t];
+            }
+        }
+        wave_global_sync();
+
+        const double rr = mfg_factor_solve(slot, nc, nrows, lane, yb);
+        wave_lds_sync();
+        // ---- residuals on the cell rows, weights ---------------------------------------------------------------------------
+        const double rri = fast_rcp(rr);
+        const bool ok = rr > 0.0;                                // rank-deficient system (or NaN from a zero column): the zero row
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (16 * pass < F) {
+                // r_e = 1 - d_e . y_e = 1 - z . b_e + u . y_dense: the c lane brings 1 - s, the three others their block of u . y
+                const int sl = (int)slot_[pass];
+                double part = fma(u[pass][2], yb[3 * sl + 2], fma(u[pass][1], yb[3 * sl + 1], u[pass][0] * yb[3 * sl]));
+                part = jq == 0 ? 1.0 - u[pass][0] : part;
+                part += dpp_mov<0xB1>(part);
+                part += dpp_mov<0x4E>(part);
+                double we = part * rri;
+                we = (ok && __builtin_isfinite(we)) ? we : 0.0;
+                if (16 * pass + fq < F && jq == 0) wbuf[pe_[pass]] = we;
+            }
+        }
+        {
+            const int ld = lane < D ? lane : 0;
+            const double ro = 1.0 - fma(dod[2], yb[3 * ld + 2], fma(dod[1], yb[3 * ld + 1], dod[0] * yb[3 * ld]));
+            double wo = ro * rri;
+            wo = (ok && __builtin_isfinite(wo)) ? wo : 0.0;
+            if (lane < D) wbuf[po] = wo;
+        }
+        wave_lds_sync();
+        {
+            // gls.pyx:470-472 (only if an interior node carries the Neumann flag): neumann_ws = the last cell's weight
+            const double nwv = is_neu ? wbuf[ne - 1] : 0.0;
+            const double addv = add_neumann ? nwv : 0.0;
+            if (lane < ne) out[eb + lane] = wbuf[lane] + addv;
+            if (lane == 0) nws[p] = nwv;
+        }
+        wave_lds_sync();
+    }
+}
+
+__global__ void k_mfg_desc(GridView g, const int32_t *__restrict__ nodes, int32_t count, uint32_t *__restrict__ desc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w[kMfgDescWords];
+    if (!mfg_descriptor(g, nodes ? nodes[i] : (int32_t)i, w)) {   // (the list holds classified nodes only)
+        for (int k = 0; k < kMfgDescWords; ++k) w[k] = 0u;
+    }
+    for (int k = 0; k < kMfgDescWords; ++k) desc[(size_t)kMfgDescWords * i + k] = w[k];
+}
+
+}  // namespace
+
+int launch_mfg_desc(const GridView &g, const int32_t *nodes, int32_t count, uint32_t *desc, hipStream_t stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_mfg_desc, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, g, nodes, count, desc);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// `tiles`: n_slots slots of kMfgSlotDoubles doubles (one per resident wavefront); at most n_slots workgroups are launched
+int launch_gls_mfg(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int add_neumann, double *out, double *nws,
+                   int32_t *queue, double *tiles, int32_t n_slots, hipStream_t stream) {
+    if (count <= 0) return 0;
+    if (!tiles || n_slots <= 0) return -1;
+    const int64_t blocks = count < n_slots ? count : n_slots;
+    hipLaunchKernelGGL(nin_gls_mfg_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, desc, count, add_neumann, out, nws, queue, tiles);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+const char *kernel_name_gls_mfg() { return "nin_gls_mfg_kernel"; }
+
+}  // namespace nin

@@ -48,6 +48,13 @@ int launch_mfx_desc(const GridView &g, const int32_t *nodes, int32_t count, uint
 int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int cls, int add_neumann, double *out,
                    double *nws, int32_t *queue, hipStream_t stream);
 const char *kernel_name_gls_mfx();
+// interior nodes beyond the wide kernel's limits (kernels_gls_mfg.hip: up to 32 fronts + 40 dense cells; the tiles of the dense problem in a
+// global-memory slot per resident wavefront); `desc` = kMfgDescWords (124) words per list entry (mfg_desc.hpp, filled by launch_mfg_desc);
+// `tiles` = n_slots slots of kMfgSlotDoubles doubles; `queue`: one zeroed device int
+int launch_mfg_desc(const GridView &g, const int32_t *nodes, int32_t count, uint32_t *desc, hipStream_t stream);
+int launch_gls_mfg(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int add_neumann, double *out, double *nws,
+                   int32_t *queue, double *tiles, int32_t n_slots, hipStream_t stream);
+const char *kernel_name_gls_mfg();
 // quad nodes (kernels_gls_quad4.hip: 4 cells, 4 internal + 4 boundary faces -- the nodes inside a boundary face of a hexahedron
 // mesh): 2 lanes per node; `desc` = 2 descriptor words per list entry (quad4_desc.hpp), filled by launch_quad4_desc
 int launch_quad4_desc(const GridView &g, const int32_t *nodes, int32_t count, int32_t *desc, hipStream_t stream);
