@@ -691,11 +691,12 @@ static int launch_class(DeviceGrid &d, int c, const int32_t *nodes, int32_t coun
                             d.gls_scratch_stride, d.gls_scratch_slots, stream);
 }
 
-// The global-scratch class first, on the side stream: entries [b, b + n) of its list.  Ordered behind everything enqueued on
-// `stream` so far (the zeroed work counters, the caller's buffers) and joined by gls_side_end.  NIN_GLS_NO_SIDE_STREAM=1: off.
-static int gls_side_begin(DeviceGrid &d, int add_neumann, double *out, double *nws, hipStream_t stream, int32_t b, int32_t n) {
+// The long poles first, on the side stream: entries [b, b + n) of the global-scratch class's list and [bg, bg + ng) of kernels_gls_mfg.hip's
+// (a node on global-memory tiles takes ~0.5 ms on a wavefront of its own).  Ordered behind everything enqueued on `stream` so far (the
+// zeroed work counters, the caller's buffers) and joined by gls_side_end.  NIN_GLS_NO_SIDE_STREAM=1: off.
+static int gls_side_begin(DeviceGrid &d, int add_neumann, double *out, double *nws, hipStream_t stream, int32_t b, int32_t n, int32_t bg, int32_t ng) {
     d.side_pending = false;
-    if (n <= 0 || getenv("NIN_GLS_NO_SIDE_STREAM") != nullptr) return 0;
+    if ((n <= 0 && ng <= 0) || getenv("NIN_GLS_NO_SIDE_STREAM") != nullptr) return 0;
     if (!d.side_stream) {
         hipStream_t s = nullptr;
         hipEvent_t a = nullptr, e = nullptr;
@@ -708,7 +709,11 @@ static int gls_side_begin(DeviceGrid &d, int add_neumann, double *out, double *n
     if (hipEventRecord(static_cast<hipEvent_t>(d.ev_fork), stream) != hipSuccess || hipStreamWaitEvent(side, static_cast<hipEvent_t>(d.ev_fork), 0) != hipSuccess)
         return -3;
     const auto &k = d.gls[kGlsClasses - 1];
-    int rc = launch_gls_class(d.v, k.nodes ? k.nodes + b : nullptr, n, 0, k.rows_per_lane, add_neumann, out, nws, d.gls_scratch, d.gls_scratch_stride,
+    int rc = 0;
+    if (ng > 0)
+        rc = launch_gls_mfg(d.v, d.mfg.nodes + bg, d.mfg_desc + (size_t)kMfgDescWords * bg, ng, add_neumann, out, nws, d.gls_queue + 14, d.mfg_tiles, d.mfg_slots, side);
+    if (!rc && n > 0)
+        rc = launch_gls_class(d.v, k.nodes ? k.nodes + b : nullptr, n, 0, k.rows_per_lane, add_neumann, out, nws, d.gls_scratch, d.gls_scratch_stride,
                               d.gls_scratch_slots, side);
     if (!rc && hipEventRecord(static_cast<hipEvent_t>(d.ev_join), side) != hipSuccess) rc = -3;
     d.side_pending = rc == 0;
@@ -740,7 +745,7 @@ static int launch_gls_but_cube(DeviceGrid &d, int add_neumann, double *out, doub
     if (!rc && on(12)) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, out, nws, stream);
     for (int i = 0; i < DeviceGrid::kMfxLists && !rc; ++i)   // (work counters: ints 8 .. 13)
         if (on(13 + i)) rc = launch_gls_mfx(d.v, d.mfx[i].nodes, d.mfx_desc[i], d.mfx[i].count, i, add_neumann, out, nws, d.gls_queue + 8 + i, stream);
-    if (!rc && on(19))   // (work counter: int 14)
+    if (!rc && on(19) && !d.side_pending)   // (work counter: int 14)
         rc = launch_gls_mfg(d.v, d.mfg.nodes, d.mfg_desc, d.mfg.count, add_neumann, out, nws, d.gls_queue + 14, d.mfg_tiles, d.mfg_slots, stream);
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         if ((c == kGlsClasses - 1 && d.side_pending) || !on(c)) continue;
@@ -773,7 +778,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else {
             HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
             const int only = gls_only();
-            if (only < 0) rc = gls_side_begin(d, add_neumann, dev_csr_data, dev_neumann_ws, stream, 0, d.gls[kGlsClasses - 1].count);
+            if (only < 0) rc = gls_side_begin(d, add_neumann, dev_csr_data, dev_neumann_ws, stream, 0, d.gls[kGlsClasses - 1].count, 0, d.mfg.count);
             if (!rc && (only < 0 || only == 5))
                 rc = launch_hex8(d, d.hex8.nodes, d.hex8_desc, d.hex8.count, add_neumann, dev_csr_data, dev_neumann_ws, stream);
             if (!rc) rc = launch_gls_but_cube(d, add_neumann, dev_csr_data, dev_neumann_ws, stream);
@@ -998,8 +1003,9 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
         return launch_rows_range(d.v, method == NIN_METHOD_LS ? 1 : 0, P, d.chunk_node[k], d.chunk_node[k + 1],
                                  (int32_t)g->h.mx_elems_per_point, out, nws, stream);
     HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
+    constexpr int lg = kGlsClasses + 8 + DeviceGrid::kMfxLists;   // kernels_gls_mfg.hip's list
     int rc = gls_side_begin(d, 1, out, nws, stream, d.chunk_off[kGlsClasses - 1][k],
-                            d.chunk_off[kGlsClasses - 1][k + 1] - d.chunk_off[kGlsClasses - 1][k]);
+                            d.chunk_off[kGlsClasses - 1][k + 1] - d.chunk_off[kGlsClasses - 1][k], d.chunk_off[lg][k], d.chunk_off[lg][k + 1] - d.chunk_off[lg][k]);
     {
         const int32_t b = d.chunk_off[kGlsClasses][k], n = d.chunk_off[kGlsClasses][k + 1] - b;
         if (!rc && n > 0) rc = launch_gls_hex8mf(d.v, d.hex8.nodes + b, d.hex8_desc + 4 * (size_t)b, n, 1, out, nws, d.gls_queue, stream);
@@ -1021,7 +1027,7 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
         const int32_t b = d.chunk_off[kGlsClasses + 8 + i][k], n = d.chunk_off[kGlsClasses + 8 + i][k + 1] - b;
         if (n > 0) rc = launch_gls_mfx(d.v, d.mfx[i].nodes + b, d.mfx_desc[i] + (size_t)kMfxDescWords * b, n, i, 1, out, nws, d.gls_queue + 8 + i, stream);
     }
-    if (!rc) {
+    if (!rc && !d.side_pending) {
         constexpr int li = kGlsClasses + 8 + DeviceGrid::kMfxLists;
         const int32_t b = d.chunk_off[li][k], n = d.chunk_off[li][k + 1] - b;
         if (n > 0) rc = launch_gls_mfg(d.v, d.mfg.nodes + b, d.mfg_desc + (size_t)kMfgDescWords * b, n, 1, out, nws, d.gls_queue + 14, d.mfg_tiles, d.mfg_slots, stream);
@@ -1191,7 +1197,7 @@ int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t
         if (!d.have_perm) return fail(NIN_ESTATE, "GLS needs permeability and diff_mag");
         if (d.gls_too_large) return fail(NIN_ERANGE, "a node's GLS system has more than 1024 rows: beyond the fallback kernel");
         HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));
-        int rc = gls_side_begin(d, 1, d.apply_weights, dev_neumann_ws, stream, 0, d.gls[kGlsClasses - 1].count);
+        int rc = gls_side_begin(d, 1, d.apply_weights, dev_neumann_ws, stream, 0, d.gls[kGlsClasses - 1].count, 0, d.mfg.count);
         if (!rc) rc = launch_gls_hex8mf_apply(d.v, d.hex8.nodes, d.hex8_desc, d.hex8.count, 1, dev_u_cells, n_fields, dev_node_values,
                                               dev_neumann_ws, d.gls_queue, stream);
         if (!rc) rc = launch_gls_but_cube(d, 1, d.apply_weights, dev_neumann_ws, stream);

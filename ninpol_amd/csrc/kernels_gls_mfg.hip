@@ -88,60 +88,104 @@ __device__ __forceinline__ void gpanel_step(double (&P)[GQ], double (&xm)[GQ], d
     }
 }
 
+// the four steps (or fewer) of a panel on its tiles P; on exit P[0] = the pivot tile (R in and above the pivot quad), vp / Tr as strip_panel's
+__device__ __forceinline__ void gpanel(double (&P)[GQ], double (&vp)[4], double (&Tr)[4], int steps, int cnt, int bp, int si, int sb, int sj) {
+    double xm[GQ];
+    gpanel_step<0>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
+    if (steps > 1) gpanel_step<1>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
+    if (steps > 2) gpanel_step<2>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
+    if (steps > 3) gpanel_step<3>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
+}
+
+// P (a factored panel of four reflectors) becomes V: below the pivots the panel's columns are the reflectors; in the pivot quad the diagonal
+// takes v's pivot entries, everything above it (R) and every row above the quad (earlier panels' rows of R) is zero.  VT = V^T per quad (the A
+// operand of C -= V W'); returns -T as a strip.
+__device__ __forceinline__ double gpanel_v(double (&P)[GQ], double (&VT)[GQ], const double (&vp)[4], const double (&Tr)[4], int cnt, int bp, int si,
+                                           int sb, int sj, double eye) {
+    const double vdiag = sj == 0 ? vp[0] : sj == 1 ? vp[1] : sj == 2 ? vp[2] : vp[3];
+    double v0 = P[0];
+    v0 = (sb == bp && si == sj) ? vdiag : v0;
+    v0 = (sb < bp || (sb == bp && si < sj)) ? 0.0 : v0;
+    P[0] = v0;
+#pragma unroll
+    for (int k = 0; k < GQ; ++k)
+        if (k < cnt) VT[k] = mfma4(P[k], eye, 0.0);
+    return -(sj == 0 ? Tr[0] : sj == 1 ? Tr[1] : sj == 2 ? Tr[2] : Tr[3]);
+}
+
+// C -= V T^T V^T C on one column block's tiles
+__device__ __forceinline__ void gpanel_apply(const double (&V)[GQ], const double (&VT)[GQ], double Ts, double (&C)[GQ], int cnt) {
+    double W = 0.0;
+#pragma unroll
+    for (int k = 0; k < GQ; ++k)
+        if (k < cnt) W = mfma4(V[k], C[k], W);
+    W = mfma4(Ts, sum_quads(W), 0.0);                            // -(T^T V^T C), the same in every quad
+#pragma unroll
+    for (int k = 0; k < GQ; ++k)
+        if (k < cnt) C[k] = mfma4(VT[k], W, C[k]);
+}
+
 // Factor the nrows x (nc + 1) problem held in the slot (c at column nc), solve R y = Q^T c: y -> yb (LDS), returns r . r.
+// The panels go in PAIRS (2 h, 2 h + 1: both pivot in tile h >> 1): a trailing column block is read once, takes both panels' reflectors
+// and is written once -- half the traffic of a panel at a time.
 __device__ __forceinline__ double mfg_factor_solve(double *__restrict__ slot, int nc, int nrows, int lane, double *yb) {
     const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3, rowbase = 4 * sb + si;
     const double eye = si == sj ? 1.0 : 0.0;
     const int n_panels = (nc + 3) >> 2, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
     double *const mine = slot + lane;
-    for (int p = 0; p < n_panels; ++p) {
-        const int q0 = p >> 2, bp = p & 3, steps = nc - 4 * p < 4 ? nc - 4 * p : 4, cnt = nq - q0;
-        double P[GQ], xm[GQ], vp[4] = {0.0, 0.0, 0.0, 0.0}, Tr[4] = {0.0, 0.0, 0.0, 0.0};
-        double *const pb = mine + ((p * GQ + q0) << 6);
+    for (int p = 0; p < n_panels; p += 2) {
+        const int q0 = p >> 2, bp = p & 3, cnt = nq - q0;
+        const int steps_a = nc - 4 * p < 4 ? nc - 4 * p : 4;
+        double VA[GQ], VTA[GQ], vp[4] = {0.0, 0.0, 0.0, 0.0}, Tr[4] = {0.0, 0.0, 0.0, 0.0};
+        double *const pa = mine + ((p * GQ + q0) << 6);
 #pragma unroll
         for (int k = 0; k < GQ; ++k) {
-            P[k] = 0.0;
-            if (k < cnt) P[k] = pb[k << 6];
+            VA[k] = 0.0;
+            if (k < cnt) VA[k] = pa[k << 6];
         }
-        gpanel_step<0>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
-        if (steps > 1) gpanel_step<1>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
-        if (steps > 2) gpanel_step<2>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
-        if (steps > 3) gpanel_step<3>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
-        pb[0] = P[0];                                            // the panel's rows of R (and, in a last panel with c in its block, Q^T c)
-        if (steps < 4) {                                         // ... whose rows below the pivots count in r . r
+        gpanel(VA, vp, Tr, steps_a, cnt, bp, si, sb, sj);
+        pa[0] = VA[0];                                           // the panel's rows of R (and, in a last panel with c in its block, Q^T c)
+        if (steps_a < 4) {                                       // ... whose rows below the pivots count in r . r
 #pragma unroll
             for (int k = 1; k < GQ; ++k)
-                if (k < cnt) pb[k << 6] = P[k];
+                if (k < cnt) pa[k << 6] = VA[k];
+            break;
         }
-        if (steps == 4 && p + 1 < ncb) {
-            {
-                // P becomes V: below the pivots the panel's columns are the reflectors; in the pivot quad the diagonal takes v's pivot
-                // entries, everything above it (R) and every row above the quad (earlier panels' rows of R) is zero
-                const double vdiag = sj == 0 ? vp[0] : sj == 1 ? vp[1] : sj == 2 ? vp[2] : vp[3];
-                double v0 = P[0];
-                v0 = (sb == bp && si == sj) ? vdiag : v0;
-                v0 = (sb < bp || (sb == bp && si < sj)) ? 0.0 : v0;
-                P[0] = v0;
-            }
-            const double Ts = -(sj == 0 ? Tr[0] : sj == 1 ? Tr[1] : sj == 2 ? Tr[2] : Tr[3]);
-            double VT[GQ];                                       // V^T per quad: the A operand of C -= V W'
+        const double TsA = gpanel_v(VA, VTA, vp, Tr, cnt, bp, si, sb, sj, eye);
+        // the block of panel p + 1 (or c's, behind the last panel): panel p's reflectors, then its own factorisation
+        double VB[GQ], VTB[GQ];
+        double *const pb = mine + (((p + 1) * GQ + q0) << 6);
+#pragma unroll
+        for (int k = 0; k < GQ; ++k) {
+            VB[k] = 0.0;
+            if (k < cnt) VB[k] = pb[k << 6];
+        }
+        gpanel_apply(VA, VTA, TsA, VB, cnt);
+        const int steps_b = p + 1 >= n_panels ? 0 : nc - 4 * (p + 1) < 4 ? nc - 4 * (p + 1) : 4;
+        if (steps_b > 0) {
+            vp[0] = vp[1] = vp[2] = vp[3] = 0.0;
+            Tr[0] = Tr[1] = Tr[2] = Tr[3] = 0.0;
+            gpanel(VB, vp, Tr, steps_b, cnt, bp + 1, si, sb, sj);
+        }
+        pb[0] = VB[0];
+        if (steps_b < 4) {
+#pragma unroll
+            for (int k = 1; k < GQ; ++k)
+                if (k < cnt) pb[k << 6] = VB[k];
+            break;
+        }
+        const double TsB = gpanel_v(VB, VTB, vp, Tr, cnt, bp + 1, si, sb, sj, eye);
+        for (int cb = p + 2; cb < ncb; ++cb) {
+            double *const cp = mine + ((cb * GQ + q0) << 6);
+            double Ct[GQ];
 #pragma unroll
             for (int k = 0; k < GQ; ++k)
-                if (k < cnt) VT[k] = mfma4(P[k], eye, 0.0);
-            for (int cb = p + 1; cb < ncb; ++cb) {
-                double *const cp = mine + ((cb * GQ + q0) << 6);
-                double Ct[GQ], W = 0.0;
+                if (k < cnt) Ct[k] = cp[k << 6];
+            gpanel_apply(VA, VTA, TsA, Ct, cnt);
+            gpanel_apply(VB, VTB, TsB, Ct, cnt);
 #pragma unroll
-                for (int k = 0; k < GQ; ++k)
-                    if (k < cnt) Ct[k] = cp[k << 6];
-#pragma unroll
-                for (int k = 0; k < GQ; ++k)
-                    if (k < cnt) W = mfma4(P[k], Ct[k], W);
-                W = mfma4(Ts, sum_quads(W), 0.0);                // -(T^T V^T C), the same in every quad
-#pragma unroll
-                for (int k = 0; k < GQ; ++k)
-                    if (k < cnt) cp[k << 6] = mfma4(VT[k], W, Ct[k]);
-            }
+            for (int k = 0; k < GQ; ++k)
+                if (k < cnt) cp[k << 6] = Ct[k];
         }
     }
     // c sits in block nc >> 2, column nc & 3
