@@ -48,24 +48,40 @@ __device__ __forceinline__ void wave_global_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// One step K of a panel whose pivot rows are quad bp of its first tile: P[k] = the panel block of tile q0 + k, k < cnt.
-// As strip_panel_step (mfw_strips.hpp), the tile loops behind wave-uniform guards.
-template <int K>
-__device__ __forceinline__ void gpanel_step(double (&P)[GQ], double (&xm)[GQ], double (&vp)[4], double (&Tr)[4], int cnt, int bp, int si, int sb,
-                                            int sj) {
+#ifndef NIN_MFG_WAVES
+#define NIN_MFG_WAVES 2   // wavefronts per SIMD
+#endif
+#ifdef NIN_MFG_STAMPS   // measurement build (tools/stamps_mfg.py): one wavefront's cycles by phase, written over the node's row of weights
+struct GStamps { unsigned long long last, acc[8]; };
+#define NIN_GST(ST, J) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); (ST).acc[J] += t_ - (ST).last; (ST).last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+struct GStamps { };
+#define NIN_GST(ST, J) do { } while (0)
+#endif
+#ifndef NIN_MFG_GROUP
+#define NIN_MFG_GROUP 4
+#endif
+constexpr int GW = NIN_MFG_GROUP;   // column blocks of a group (4: 16 columns, four panels, all pivoting in the same row tile)
+static_assert(GW == 4 || GW == 2 || GW == 1, "a group's panels pivot in one row tile");
+
+// One step K of panel J of a group: C[k][J] = the panel block of row tile k; the pivot rows are quad bp of tile q0.  As strip_panel_step
+// (mfw_strips.hpp), the tile loops behind wave-uniform guards.
+template <int K, int J>
+__device__ __forceinline__ void gpanel_step(double (&C)[GQ][GW], double &PT, double (&xm)[GQ], double (&vp)[4], double (&Tr)[4], int q0, int nq, int bp,
+                                            int si, int sb, int sj) {
     const bool in_piv_quad = sb == bp;
     const bool is_piv = in_piv_quad && si == K;
     const bool below0 = sb > bp || (in_piv_quad && si > K);
-    xm[0] = below0 ? quad_pick<K>(P[0]) : 0.0;
-    double acc = xm[0] * P[0];
+    const double xm0 = below0 ? quad_pick<K>(PT) : 0.0;
+    double acc = xm0 * PT;
 #pragma unroll
     for (int k = 1; k < GQ; ++k) {
-        if (k < cnt) {
-            xm[k] = quad_pick<K>(P[k]);
-            acc = fma(xm[k], P[k], acc);
+        if (k > q0 && k < nq) {
+            xm[k] = quad_pick<K>(C[k][J]);
+            acc = fma(xm[k], C[k][J], acc);
         }
     }
-    const double ap = __shfl(P[0], 16 * K + 4 * bp + sj);        // the pivot row's entry of column j
+    const double ap = __shfl(PT, 16 * K + 4 * bp + sj);          // the pivot row's entry of column j
     const double d = sum_rows(sum_quads(acc));
     const House h = house_unguarded(quad_pick<K>(ap), quad_pick<K>(d));
     const double e = fma(h.vp, ap, d);
@@ -79,118 +95,154 @@ __device__ __forceinline__ void gpanel_step(double (&P)[GQ], double (&xm)[GQ], d
         Tr[K] = si == K ? h.g : -(h.g * t);
     }
     {
-        const double x = fma(w, is_piv ? h.vp : xm[0], P[0]);
-        P[0] = (is_piv && sj == K) ? h.beta : x;
+        const double x = fma(w, is_piv ? h.vp : xm0, PT);
+        PT = (is_piv && sj == K) ? h.beta : x;
     }
 #pragma unroll
     for (int k = 1; k < GQ; ++k) {
-        if (k < cnt) P[k] = fma(w, xm[k], P[k]);
+        if (k > q0 && k < nq) C[k][J] = fma(w, xm[k], C[k][J]);
     }
 }
 
-// the four steps (or fewer) of a panel on its tiles P; on exit P[0] = the pivot tile (R in and above the pivot quad), vp / Tr as strip_panel's
-__device__ __forceinline__ void gpanel(double (&P)[GQ], double (&vp)[4], double (&Tr)[4], int steps, int cnt, int bp, int si, int sb, int sj) {
-    double xm[GQ];
-    gpanel_step<0>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
-    if (steps > 1) gpanel_step<1>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
-    if (steps > 2) gpanel_step<2>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
-    if (steps > 3) gpanel_step<3>(P, xm, vp, Tr, cnt, bp, si, sb, sj);
+// a stored pivot tile -> the reflectors' entries in it: zero above the diagonal of the pivot quad and in the rows above the quad (R lives
+// there), the diagonal = v's pivot entries
+__device__ __forceinline__ double pivot_tile_v(double t, double vdiag, int bp, int si, int sb, int sj) {
+    t = (sb == bp && si == sj) ? vdiag : t;
+    return (sb < bp || (sb == bp && si < sj)) ? 0.0 : t;
 }
 
-// P (a factored panel of four reflectors) becomes V: below the pivots the panel's columns are the reflectors; in the pivot quad the diagonal
-// takes v's pivot entries, everything above it (R) and every row above the quad (earlier panels' rows of R) is zero.  VT = V^T per quad (the A
-// operand of C -= V W'); returns -T as a strip.
-__device__ __forceinline__ double gpanel_v(double (&P)[GQ], double (&VT)[GQ], const double (&vp)[4], const double (&Tr)[4], int cnt, int bp, int si,
-                                           int sb, int sj, double eye) {
+// C(:, block JJ) -= V T^T V^T C(:, block JJ) for the blocks J0 .. GW - 1 of the group; V[k] = the reflectors' tile k (k >= q0)
+template <int J0>
+__device__ __forceinline__ void group_apply(const double (&V)[GQ], double Ts, double (&C)[GQ][GW], int q0, int nq, double eye) {
+    double W[GW];
+#pragma unroll
+    for (int j = J0; j < GW; ++j) W[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < GQ; ++k) {
+        if (k >= q0 && k < nq) {
+#pragma unroll
+            for (int j = J0; j < GW; ++j) W[j] = mfma4(V[k], C[k][j], W[j]);
+        }
+    }
+#pragma unroll
+    for (int j = J0; j < GW; ++j) W[j] = mfma4(Ts, sum_quads(W[j]), 0.0);   // -(T^T V^T C), the same in every quad
+#pragma unroll
+    for (int k = 0; k < GQ; ++k) {
+        if (k >= q0 && k < nq) {
+            const double VT = mfma4(V[k], eye, 0.0);             // V^T per quad: the A operand of C -= V W'
+#pragma unroll
+            for (int j = J0; j < GW; ++j) C[k][j] = mfma4(VT, W[j], C[k][j]);
+        }
+    }
+}
+
+// Panel J of group g (block 4 g + J): factor it in place, leave T and v's pivot entries in the panel's two auxiliary tiles, apply it to the
+// group's blocks right of it.  false: this was the last panel (fewer than four pivots: c sits in its block).
+template <int J>
+__device__ __forceinline__ bool group_panel(double (&C)[GQ][GW], double *mine, int g, int nc, int nq, int si, int sb, int sj, double eye, GStamps &ST) {
+    const int p = GW * g + J, steps = nc - 4 * p < 4 ? nc - 4 * p : 4, q0 = p >> 2, bp = p & 3;
+    if (steps <= 0) return false;
+    double xm[GQ], vp[4] = {0.0, 0.0, 0.0, 0.0}, Tr[4] = {0.0, 0.0, 0.0, 0.0};
+    double PT = 0.0;
+#pragma unroll
+    for (int k = 0; k < GQ; ++k)
+        if (k == q0) PT = C[k][J];
+    gpanel_step<0, J>(C, PT, xm, vp, Tr, q0, nq, bp, si, sb, sj);
+    if (steps > 1) gpanel_step<1, J>(C, PT, xm, vp, Tr, q0, nq, bp, si, sb, sj);
+    if (steps > 2) gpanel_step<2, J>(C, PT, xm, vp, Tr, q0, nq, bp, si, sb, sj);
+    if (steps > 3) gpanel_step<3, J>(C, PT, xm, vp, Tr, q0, nq, bp, si, sb, sj);
+#pragma unroll
+    for (int k = 0; k < GQ; ++k)
+        if (k == q0) C[k][J] = PT;
+    NIN_GST(ST, 3);
+    if (steps < 4) return false;
+    const double Ts = -(sj == 0 ? Tr[0] : sj == 1 ? Tr[1] : sj == 2 ? Tr[2] : Tr[3]);
     const double vdiag = sj == 0 ? vp[0] : sj == 1 ? vp[1] : sj == 2 ? vp[2] : vp[3];
-    double v0 = P[0];
-    v0 = (sb == bp && si == sj) ? vdiag : v0;
-    v0 = (sb < bp || (sb == bp && si < sj)) ? 0.0 : v0;
-    P[0] = v0;
+    mine[(GQ * GCB + 2 * p) << 6] = Ts;
+    mine[(GQ * GCB + 2 * p + 1) << 6] = vdiag;
+    if constexpr (J + 1 < GW) {
+        double V[GQ];
 #pragma unroll
-    for (int k = 0; k < GQ; ++k)
-        if (k < cnt) VT[k] = mfma4(P[k], eye, 0.0);
-    return -(sj == 0 ? Tr[0] : sj == 1 ? Tr[1] : sj == 2 ? Tr[2] : Tr[3]);
-}
-
-// C -= V T^T V^T C on one column block's tiles
-__device__ __forceinline__ void gpanel_apply(const double (&V)[GQ], const double (&VT)[GQ], double Ts, double (&C)[GQ], int cnt) {
-    double W = 0.0;
-#pragma unroll
-    for (int k = 0; k < GQ; ++k)
-        if (k < cnt) W = mfma4(V[k], C[k], W);
-    W = mfma4(Ts, sum_quads(W), 0.0);                            // -(T^T V^T C), the same in every quad
-#pragma unroll
-    for (int k = 0; k < GQ; ++k)
-        if (k < cnt) C[k] = mfma4(VT[k], W, C[k]);
+        for (int k = 0; k < GQ; ++k) V[k] = k == q0 ? pivot_tile_v(PT, vdiag, bp, si, sb, sj) : C[k][J];
+        group_apply<J + 1>(V, Ts, C, q0, nq, eye);
+    }
+    NIN_GST(ST, 4);
+    return true;
 }
 
 // Factor the nrows x (nc + 1) problem held in the slot (c at column nc), solve R y = Q^T c: y -> yb (LDS), returns r . r.
-// The panels go in PAIRS (2 h, 2 h + 1: both pivot in tile h >> 1): a trailing column block is read once, takes both panels' reflectors
-// and is written once -- half the traffic of a panel at a time.
-__device__ __forceinline__ double mfg_factor_solve(double *__restrict__ slot, int nc, int nrows, int lane, double *yb) {
+// LEFT-LOOKING by groups of four column blocks: a group's 4 x nq tiles are read once, take the reflectors of every panel left of the group
+// (read back from where the panels were factored: V below R in the panel's own tiles, T and v's pivot entries in two auxiliary tiles per
+// panel), are factored -- four panels, each applied to the blocks right of it in the registers -- and written once.  Nothing but finished
+// panels is ever re-read: per node ~0.6 MB of traffic against 2.5 MB of the right-looking form a panel at a time, and no load waits for a
+// store.
+__device__ __forceinline__ double mfg_factor_solve(double *__restrict__ slot, int nc, int nrows, int lane, double *yb, GStamps &ST) {
     const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3, rowbase = 4 * sb + si;
     const double eye = si == sj ? 1.0 : 0.0;
-    const int n_panels = (nc + 3) >> 2, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
+    const int n_panels = (nc + 3) >> 2, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2, n_groups = (ncb + GW - 1) / GW;
     double *const mine = slot + lane;
-    for (int p = 0; p < n_panels; p += 2) {
-        const int q0 = p >> 2, bp = p & 3, cnt = nq - q0;
-        const int steps_a = nc - 4 * p < 4 ? nc - 4 * p : 4;
-        double VA[GQ], VTA[GQ], vp[4] = {0.0, 0.0, 0.0, 0.0}, Tr[4] = {0.0, 0.0, 0.0, 0.0};
-        double *const pa = mine + ((p * GQ + q0) << 6);
+    for (int g = 0; g < n_groups; ++g) {
+        double C[GQ][GW];
+        double *const gp = mine + ((GW * g * GQ) << 6);
 #pragma unroll
-        for (int k = 0; k < GQ; ++k) {
-            VA[k] = 0.0;
-            if (k < cnt) VA[k] = pa[k << 6];
-        }
-        gpanel(VA, vp, Tr, steps_a, cnt, bp, si, sb, sj);
-        pa[0] = VA[0];                                           // the panel's rows of R (and, in a last panel with c in its block, Q^T c)
-        if (steps_a < 4) {                                       // ... whose rows below the pivots count in r . r
-#pragma unroll
-            for (int k = 1; k < GQ; ++k)
-                if (k < cnt) pa[k << 6] = VA[k];
-            break;
-        }
-        const double TsA = gpanel_v(VA, VTA, vp, Tr, cnt, bp, si, sb, sj, eye);
-        // the block of panel p + 1 (or c's, behind the last panel): panel p's reflectors, then its own factorisation
-        double VB[GQ], VTB[GQ];
-        double *const pb = mine + (((p + 1) * GQ + q0) << 6);
-#pragma unroll
-        for (int k = 0; k < GQ; ++k) {
-            VB[k] = 0.0;
-            if (k < cnt) VB[k] = pb[k << 6];
-        }
-        gpanel_apply(VA, VTA, TsA, VB, cnt);
-        const int steps_b = p + 1 >= n_panels ? 0 : nc - 4 * (p + 1) < 4 ? nc - 4 * (p + 1) : 4;
-        if (steps_b > 0) {
-            vp[0] = vp[1] = vp[2] = vp[3] = 0.0;
-            Tr[0] = Tr[1] = Tr[2] = Tr[3] = 0.0;
-            gpanel(VB, vp, Tr, steps_b, cnt, bp + 1, si, sb, sj);
-        }
-        pb[0] = VB[0];
-        if (steps_b < 4) {
-#pragma unroll
-            for (int k = 1; k < GQ; ++k)
-                if (k < cnt) pb[k << 6] = VB[k];
-            break;
-        }
-        const double TsB = gpanel_v(VB, VTB, vp, Tr, cnt, bp + 1, si, sb, sj, eye);
-        for (int cb = p + 2; cb < ncb; ++cb) {
-            double *const cp = mine + ((cb * GQ + q0) << 6);
-            double Ct[GQ];
+        for (int j = 0; j < GW; ++j) {
 #pragma unroll
             for (int k = 0; k < GQ; ++k)
-                if (k < cnt) Ct[k] = cp[k << 6];
-            gpanel_apply(VA, VTA, TsA, Ct, cnt);
-            gpanel_apply(VB, VTB, TsB, Ct, cnt);
+                if (k < nq) C[k][j] = gp[(j * GQ + k) << 6];     // (blocks beyond the node's: zero-filled by the caller)
+        }
+        NIN_GST(ST, 1);
+        // the panels left of the group (every one of them has four reflectors); panel p + 1's tiles are on their way while panel p is applied
+        // (they are final: no store of this loop touches them)
+        double Vn[GQ], Tsn = 0.0, vdn = 0.0;
+#pragma unroll
+        for (int k = 0; k < GQ; ++k) Vn[k] = 0.0;
+        if (g > 0) {
 #pragma unroll
             for (int k = 0; k < GQ; ++k)
-                if (k < cnt) cp[k << 6] = Ct[k];
+                if (k < nq) Vn[k] = mine[k << 6];
+            Tsn = mine[(GQ * GCB) << 6];
+            vdn = mine[(GQ * GCB + 1) << 6];
+        }
+        for (int p = 0; p < GW * g; ++p) {
+            const int q0 = p >> 2, bp = p & 3;
+            double V[GQ];
+#pragma unroll
+            for (int k = 0; k < GQ; ++k) V[k] = k == q0 ? pivot_tile_v(Vn[k], vdn, bp, si, sb, sj) : Vn[k];
+            const double Ts = Tsn;
+            if (p + 1 < GW * g) {
+                const int q1 = (p + 1) >> 2;
+                const double *const vnext = mine + (((p + 1) * GQ) << 6);
+#pragma unroll
+                for (int k = 0; k < GQ; ++k)
+                    if (k >= q1 && k < nq) Vn[k] = vnext[k << 6];
+                Tsn = mine[(GQ * GCB + 2 * (p + 1)) << 6];
+                vdn = mine[(GQ * GCB + 2 * (p + 1) + 1) << 6];
+            }
+            group_apply<0>(V, Ts, C, q0, nq, eye);
+        }
+        NIN_GST(ST, 2);
+        // the group's own panels
+        if constexpr (GW == 4) {
+            if (group_panel<0>(C, mine, g, nc, nq, si, sb, sj, eye, ST))
+                if (group_panel<1>(C, mine, g, nc, nq, si, sb, sj, eye, ST))
+                    if (group_panel<2>(C, mine, g, nc, nq, si, sb, sj, eye, ST)) (void)group_panel<GW - 1>(C, mine, g, nc, nq, si, sb, sj, eye, ST);
+        } else if constexpr (GW == 2) {
+            if (group_panel<0>(C, mine, g, nc, nq, si, sb, sj, eye, ST)) (void)group_panel<GW - 1>(C, mine, g, nc, nq, si, sb, sj, eye, ST);
+        } else {
+            (void)group_panel<0>(C, mine, g, nc, nq, si, sb, sj, eye, ST);
+        }
+        NIN_GST(ST, 3);
+#pragma unroll
+        for (int j = 0; j < GW; ++j) {
+#pragma unroll
+            for (int k = 0; k < GQ; ++k)
+                if (k < nq) gp[(j * GQ + k) << 6] = C[k][j];
         }
     }
     // c sits in block nc >> 2, column nc & 3
     const int cbc = nc >> 2, jc = nc & 3;
     double *const cc = mine + ((cbc * GQ) << 6);
+    NIN_GST(ST, 1);
     double rr = 0.0;
     {
         double t = 0.0;
@@ -209,13 +261,27 @@ __device__ __forceinline__ double mfg_factor_solve(double *__restrict__ slot, in
         b[k] = 0.0;
         if (16 * k < nc) b[k] = __shfl(cc[k << 6], (lane & ~3) | jc);
     }
+    double Tn[BQ];                                               // the tiles of the next block column: on their way while this one is solved
+#pragma unroll
+    for (int k = 0; k < BQ; ++k) {
+        Tn[k] = 0.0;
+        if (k <= ((nc - 1) >> 4)) Tn[k] = mine[((((nc - 1) >> 2) * GQ + k) << 6)];
+    }
     for (int cb = (nc - 1) >> 2; cb >= 0; --cb) {
         const int q = cb >> 2, quad = cb & 3, live = nc - 4 * cb < 4 ? nc - 4 * cb : 4;   // (a last block shares its columns with c)
-        double *const cp = mine + ((cb * GQ) << 6);
-        const double Dt = cp[q << 6];
-        double bq = 0.0;
+        double T[BQ], Dt = 0.0, bq = 0.0;
 #pragma unroll
-        for (int k = 0; k < BQ; ++k) bq = k == q ? b[k] : bq;
+        for (int k = 0; k < BQ; ++k) {
+            T[k] = Tn[k];
+            Dt = k == q ? Tn[k] : Dt;
+            bq = k == q ? b[k] : bq;
+        }
+        if (cb > 0) {
+            const double *const cn = mine + (((cb - 1) * GQ) << 6);
+#pragma unroll
+            for (int k = 0; k < BQ; ++k)
+                if (k <= ((cb - 1) >> 2)) Tn[k] = cn[k << 6];
+        }
         double y[4];
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
@@ -230,8 +296,7 @@ __device__ __forceinline__ double mfg_factor_solve(double *__restrict__ slot, in
 #pragma unroll
         for (int k = 0; k < BQ; ++k) {
             if (k <= q) {                                        // the rows above the block: b -= R(:, block) y
-                const double tv = k == q ? Dt : cp[k << 6];
-                double part = tv * ysel;
+                double part = T[k] * ysel;
                 part += dpp_mov<0xB1>(part);                     // sum over the quad's four columns
                 part += dpp_mov<0x4E>(part);
                 const bool above = k < q || sb < quad;
@@ -239,10 +304,11 @@ __device__ __forceinline__ double mfg_factor_solve(double *__restrict__ slot, in
             }
         }
     }
+    NIN_GST(ST, 5);
     return rr;
 }
 
-__global__ __launch_bounds__(64, 2) void nin_gls_mfg_kernel(GridView g, const int32_t *__restrict__ nodes, const uint32_t *__restrict__ desc,
+__global__ __launch_bounds__(64, NIN_MFG_WAVES) void nin_gls_mfg_kernel(GridView g, const int32_t *__restrict__ nodes, const uint32_t *__restrict__ desc,
                                                            int32_t count, int add_neumann, double *__restrict__ out, double *__restrict__ nws,
                                                            int32_t *__restrict__ queue, double *__restrict__ tiles) {
     __shared__ double Lm[G_PER_WAVE];
@@ -258,6 +324,11 @@ __global__ __launch_bounds__(64, 2) void nin_gls_mfg_kernel(GridView g, const in
         return __builtin_amdgcn_readfirstlane(v);
     };
     for (int32_t idx = ticket(); idx < count; idx = ticket()) {
+        GStamps ST;
+#ifdef NIN_MFG_STAMPS
+        for (int k = 0; k < 8; ++k) ST.acc[k] = 0ull;
+        ST.last = __builtin_amdgcn_s_memtime();
+#endif
         const int32_t p = __builtin_amdgcn_readfirstlane(nodes ? nodes[idx] : idx);
         const uint32_t *dw = desc + (size_t)kMfgDescWords * idx;
         for (int k = lane; k < kMfgDescWords; k += 64) dl[k] = dw[k];
@@ -269,25 +340,25 @@ __global__ __launch_bounds__(64, 2) void nin_gls_mfg_kernel(GridView g, const in
         const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1], xv2 = g.coords[3 * (size_t)p + 2];
         const int nc = 3 * D, nrows = 7 * F + D + 3 * nfree, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2;
         // the tiles of this node: zero (a lane clears its own element of every tile)
-        for (int cb = 0; cb < ncb; ++cb)
+        for (int cb = 0; cb < ((ncb + GW - 1) / GW) * GW; ++cb)    // (whole groups of column blocks)
             for (int q = 0; q < nq; ++q) slot[((cb * GQ + q) << 6) + lane] = 0.0;
         wave_lds_sync();
         wave_global_sync();
         // ---- phase 1: the fronts in passes of 16, FOUR lanes per front (lane 4 f + j: c for j = 0, the columns of neighbour j - 1 otherwise);
         //      the 7 fill rows of a front go straight to their elements of the tiles ------------------------------------------------
         const int fq = lane >> 2, jq = lane & 3, my = jq > 0 ? jq - 1 : 0;
-        double u[2][3];
-        uint32_t pe_[2], slot_[2];
-#pragma unroll
+        double u[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        uint32_t pe_[2] = {0u, 0u}, slot_[2] = {0u, 0u};
+#pragma unroll 1                                                 // (one body: two copies of it cost 100 registers more)
         for (int pass = 0; pass < 2; ++pass) {
-            u[pass][0] = u[pass][1] = u[pass][2] = 0.0;
-            pe_[pass] = slot_[pass] = 0u;
             if (16 * pass < F) {                                 // (wave-uniform)
                 const int f = 16 * pass + fq;
                 const uint32_t wa = dl[kMfgW0 + f], wb = dl[kMfgW1 + f];
                 const uint32_t pe = wa & 63u, myslot = (wb >> (6 * my)) & 63u;
-                pe_[pass] = pe;
-                slot_[pass] = myslot;
+                pe_[0] = pass == 0 ? pe : pe_[0];
+                pe_[1] = pass == 1 ? pe : pe_[1];
+                slot_[0] = pass == 0 ? myslot : slot_[0];
+                slot_[1] = pass == 1 ? myslot : slot_[1];
                 const uint32_t ce = (uint32_t)g.esup[eb + pe], cm = (uint32_t)g.esup[eb + slotpos[myslot]];
                 double P[10][3], B[10][3], de[3];
                 double Ke[9], Km[9];
@@ -333,7 +404,11 @@ __global__ __launch_bounds__(64, 2) void nin_gls_mfg_kernel(GridView g, const in
                 __builtin_amdgcn_sched_barrier(0);
                 apply_panel<3, true, true, true, true>(P, g3, B);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) u[pass][t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));
+                for (int t = 0; t < 3; ++t) {
+                    const double ut = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));
+                    u[0][t] = pass == 0 ? ut : u[0][t];
+                    u[1][t] = pass == 1 ? ut : u[1][t];
+                }
                 if (f < F) {
 #pragma unroll
                     for (int r = 0; r < 7; ++r) {
@@ -393,7 +468,8 @@ __global__ __launch_bounds__(64, 2) void nin_gls_mfg_kernel(GridView g, const in
         }
         wave_global_sync();
 
-        const double rr = mfg_factor_solve(slot, nc, nrows, lane, yb);
+        NIN_GST(ST, 0);
+        const double rr = mfg_factor_solve(slot, nc, nrows, lane, yb, ST);
         wave_lds_sync();
         // ---- residuals on the cell rows, weights ---------------------------------------------------------------------------
         const double rri = fast_rcp(rr);
@@ -425,6 +501,10 @@ __global__ __launch_bounds__(64, 2) void nin_gls_mfg_kernel(GridView g, const in
             const double nwv = is_neu ? wbuf[ne - 1] : 0.0;
             const double addv = add_neumann ? nwv : 0.0;
             if (lane < ne) out[eb + lane] = wbuf[lane] + addv;
+#ifdef NIN_MFG_STAMPS
+            NIN_GST(ST, 6);
+            if (lane < 8) out[eb + lane] = lane == 7 ? (double)(nq * 1000 + ncb) : (double)ST.acc[lane];
+#endif
             if (lane == 0) nws[p] = nwv;
         }
         wave_lds_sync();
