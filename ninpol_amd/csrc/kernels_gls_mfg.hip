@@ -8,13 +8,19 @@
 //   * the fronts are eliminated first, in the lanes (kernels_gls_mfx.hip's phase 1, in passes of 16 fronts): (7 F + D + 3 free) x
 //     (3 D + 1) is left -- a quarter of the entries;
 //   * the dense problem is factored in PANELS OF FOUR reflectors (compact WY, mfw_strips.hpp's strip form: the FP64 matrix unit as the
-//     cross-lane adder), so a trailing tile is read and written once per panel, not once per reflector: ~3 MB a node, every access a
-//     whole 512-byte tile (lane = element);
-//   * nothing but the panel block and one column block is in registers at a time: ~130 registers, two wavefronts per SIMD, and the loops
-//     over tiles and column blocks are ordinary run-time loops (a lane only ever touches its own element of a tile, so the tiles need no
-//     synchronisation between the panels);
-//   * R stays where the factorisation leaves it (the tiles are not shifted) and R y = Q^T c is solved block column by block column
-//     straight from the tiles.
+//     cross-lane adder), LEFT-LOOKING by groups of four column blocks: a group's tiles are read once into registers, take the reflectors
+//     of every finished panel left of the group (read back from where those panels were factored, the next panel's tiles on their way
+//     while one is applied), are factored and written once: ~0.6 MB a node, every access a whole 512-byte tile (lane = element), no
+//     load behind a store.  (Measured on the way, 1 770 nodes of the random cloud: right-looking a panel at a time -- every trailing
+//     tile read and written per panel, 2.5 MB a node -- 1.43 ms; panels in pairs 1.00 ms; left-looking 0.64 ms; the tile loops
+//     entered by chunk, the reflectors' pivot tile stored ready-made 0.51 ms.)
+//   * a lane only ever touches its own element of a tile, so the tiles need no synchronisation between the panels; the loops over panels
+//     and groups are ordinary run-time loops, the loops over a group's row tiles are unrolled behind wave-uniform guards (for_tiles_down);
+//   * R stays where the factorisation leaves it and R y = Q^T c is solved block column by block column straight from the tiles.
+// One wavefront per SIMD (443 registers: the group's 64 tiles, two panels of reflectors); a second wavefront buys nothing -- the
+// kernel is bound by instruction issue, not by latency (two wavefronts at 256 registers each: the same nodes per second).
+// tools/stamps_mfg.py (a -DNIN_MFG_STAMPS build) gives one wavefront's cycles by phase: of ~435 k per node, 137 k apply finished panels
+// to the groups, 125 k are the panels' own steps (vector work), 72 k phase 1, 41 k the back substitution.
 // Same mathematics as dgels on the reference's matrix (gls.pyx:252-474): a Householder QR under a column / row order that exposes the zeros.
 #include <hip/hip_runtime.h>
 
@@ -36,10 +42,13 @@ using namespace mfwstrips;
 constexpr int GQ = kMfgRowTiles, GCB = kMfgColBlocks;
 constexpr int G_Y = 0, G_W = 128, G_DESC = G_W + 64, G_PER_WAVE = G_DESC + kMfgDescWords / 2;   // LDS (doubles): y | weights | descriptor
 
-// element (row, col) of the dense problem in the wavefront's slot: tile (row >> 4, col >> 2) at ((col >> 2) * 16 + (row >> 4)) * 64 -- the
-// tiles of a column block lie behind one another --, lane 16 (row & 3) + 4 ((row >> 2) & 3) + (col & 3) of the tile
-__device__ __forceinline__ int tile_index(int row, int col) {
-    return ((((col >> 2) * GQ) + (row >> 4)) << 6) + 16 * (row & 3) + 4 * ((row >> 2) & 3) + (col & 3);
+// Element (row, col) of the dense problem in the wavefront's slot: row tiles are counted FROM THE BOTTOM -- kk = nq - 1 - (row >> 4), nq =
+// the node's row tiles -- so that the tiles a panel still touches are always kk = 0 .. top (top falls by one every four panels): every tile loop
+// is "kk = top down to 0", entered by ONE switch and straight-line from there (for_tiles_down) -- a lone wavefront pays ~50 cycles per taken
+// branch, and a guard per tile was a third of this kernel's time.  Tile (kk, cb) lies at ((cb * 16 + kk) * 64 (the tiles of a column block lie
+// behind one another), element = lane 16 (row & 3) + 4 ((row >> 2) & 3) + (col & 3).
+__device__ __forceinline__ int tile_index(int row, int col, int nq) {
+    return ((((col >> 2) * GQ) + (nq - 1 - (row >> 4))) << 6) + 16 * (row & 3) + 4 * ((row >> 2) & 3) + (col & 3);
 }
 
 __device__ __forceinline__ void wave_global_sync() {
@@ -49,7 +58,7 @@ __device__ __forceinline__ void wave_global_sync() {
 }
 
 #ifndef NIN_MFG_WAVES
-#define NIN_MFG_WAVES 2   // wavefronts per SIMD
+#define NIN_MFG_WAVES 1   // wavefronts per SIMD
 #endif
 #ifdef NIN_MFG_STAMPS   // measurement build (tools/stamps_mfg.py): one wavefront's cycles by phase, written over the node's row of weights
 struct GStamps { unsigned long long last, acc[8]; };
@@ -58,29 +67,44 @@ struct GStamps { unsigned long long last, acc[8]; };
 struct GStamps { };
 #define NIN_GST(ST, J) do { } while (0)
 #endif
-#ifndef NIN_MFG_GROUP
-#define NIN_MFG_GROUP 4
-#endif
-constexpr int GW = NIN_MFG_GROUP;   // column blocks of a group (4: 16 columns, four panels, all pivoting in the same row tile)
-static_assert(GW == 4 || GW == 2 || GW == 1, "a group's panels pivot in one row tile");
+constexpr int GW = 4;   // column blocks of a group (16 columns: four panels, all pivoting in the same row tile)
 
-// One step K of panel J of a group: C[k][J] = the panel block of row tile k; the pivot rows are quad bp of tile q0.  As strip_panel_step
-// (mfw_strips.hpp), the tile loops behind wave-uniform guards.
+template <int KK>
+struct TileNo { static constexpr int value = KK; };
+// f(TileNo<kk>) for kk = top, top - 1, .., 0 (top < 0: nothing; top <= 15)
+// ... in chunks of four: a chunk above `top` is skipped by one branch, inside the chunk that holds `top` at most three tiles are (a lone
+// wavefront pays ~50 cycles per TAKEN branch: 2.5 on average this way, 5.5 with a guard per tile)
+template <int K0, class F>
+__device__ __forceinline__ void tiles_chunk_down(int top, F &&f) {
+    if (top >= K0) {
+        if (top >= K0 + 3) f(TileNo<K0 + 3>{});
+        if (top >= K0 + 2) f(TileNo<K0 + 2>{});
+        if (top >= K0 + 1) f(TileNo<K0 + 1>{});
+        f(TileNo<K0>{});
+    }
+}
+template <class F>
+__device__ __forceinline__ void for_tiles_down(int top, F &&f) {
+    static_assert(GQ == 16, "four chunks of four row tiles");
+    tiles_chunk_down<12>(top, f);
+    tiles_chunk_down<8>(top, f);
+    tiles_chunk_down<4>(top, f);
+    tiles_chunk_down<0>(top, f);
+}
+
+// One step K of panel J of a group: C[kk][J] = the panel block of row tile kk; PT = the pivot tile (kk = top), the pivot rows are its quad bp.
+// As strip_panel_step (mfw_strips.hpp).
 template <int K, int J>
-__device__ __forceinline__ void gpanel_step(double (&C)[GQ][GW], double &PT, double (&xm)[GQ], double (&vp)[4], double (&Tr)[4], int q0, int nq, int bp,
-                                            int si, int sb, int sj) {
+__device__ __forceinline__ void gpanel_step(double (&C)[GQ][GW], double &PT, double (&vp)[4], double (&Tr)[4], int top, int bp, int si, int sb, int sj) {
     const bool in_piv_quad = sb == bp;
     const bool is_piv = in_piv_quad && si == K;
     const bool below0 = sb > bp || (in_piv_quad && si > K);
     const double xm0 = below0 ? quad_pick<K>(PT) : 0.0;
     double acc = xm0 * PT;
-#pragma unroll
-    for (int k = 1; k < GQ; ++k) {
-        if (k > q0 && k < nq) {
-            xm[k] = quad_pick<K>(C[k][J]);
-            acc = fma(xm[k], C[k][J], acc);
-        }
-    }
+    for_tiles_down(top - 1, [&](auto t) __attribute__((always_inline)) {
+        constexpr int kk = decltype(t)::value;
+        acc = fma(quad_pick<K>(C[kk][J]), C[kk][J], acc);
+    });
     const double ap = __shfl(PT, 16 * K + 4 * bp + sj);          // the pivot row's entry of column j
     const double d = sum_rows(sum_quads(acc));
     const House h = house_unguarded(quad_pick<K>(ap), quad_pick<K>(d));
@@ -98,174 +122,160 @@ __device__ __forceinline__ void gpanel_step(double (&C)[GQ][GW], double &PT, dou
         const double x = fma(w, is_piv ? h.vp : xm0, PT);
         PT = (is_piv && sj == K) ? h.beta : x;
     }
-#pragma unroll
-    for (int k = 1; k < GQ; ++k) {
-        if (k > q0 && k < nq) C[k][J] = fma(w, xm[k], C[k][J]);
-    }
+    for_tiles_down(top - 1, [&](auto t) __attribute__((always_inline)) {
+        constexpr int kk = decltype(t)::value;
+        C[kk][J] = fma(w, quad_pick<K>(C[kk][J]), C[kk][J]);     // (the reflector's entry again: two moves against a register per tile)
+    });
 }
 
-// a stored pivot tile -> the reflectors' entries in it: zero above the diagonal of the pivot quad and in the rows above the quad (R lives
+// a factored pivot tile -> the reflectors' entries in it: zero above the diagonal of the pivot quad and in the rows above the quad (R lives
 // there), the diagonal = v's pivot entries
 __device__ __forceinline__ double pivot_tile_v(double t, double vdiag, int bp, int si, int sb, int sj) {
     t = (sb == bp && si == sj) ? vdiag : t;
     return (sb < bp || (sb == bp && si < sj)) ? 0.0 : t;
 }
 
-// C(:, block JJ) -= V T^T V^T C(:, block JJ) for the blocks J0 .. GW - 1 of the group; V[k] = the reflectors' tile k (k >= q0)
+// C(:, block j) -= V T^T V^T C(:, block j) for the blocks J0 .. GW - 1 of the group; V[kk] = the reflectors' tile kk <= top
 template <int J0>
-__device__ __forceinline__ void group_apply(const double (&V)[GQ], double Ts, double (&C)[GQ][GW], int q0, int nq, double eye) {
+__device__ __forceinline__ void group_apply(const double (&V)[GQ], double Ts, double (&C)[GQ][GW], int top, double eye) {
     double W[GW];
 #pragma unroll
     for (int j = J0; j < GW; ++j) W[j] = 0.0;
+    for_tiles_down(top, [&](auto t) __attribute__((always_inline)) {
+        constexpr int kk = decltype(t)::value;
 #pragma unroll
-    for (int k = 0; k < GQ; ++k) {
-        if (k >= q0 && k < nq) {
-#pragma unroll
-            for (int j = J0; j < GW; ++j) W[j] = mfma4(V[k], C[k][j], W[j]);
-        }
-    }
+        for (int j = J0; j < GW; ++j) W[j] = mfma4(V[kk], C[kk][j], W[j]);
+    });
 #pragma unroll
     for (int j = J0; j < GW; ++j) W[j] = mfma4(Ts, sum_quads(W[j]), 0.0);   // -(T^T V^T C), the same in every quad
+    for_tiles_down(top, [&](auto t) __attribute__((always_inline)) {
+        constexpr int kk = decltype(t)::value;
+        const double VT = mfma4(V[kk], eye, 0.0);                // V^T per quad: the A operand of C -= V W'
 #pragma unroll
-    for (int k = 0; k < GQ; ++k) {
-        if (k >= q0 && k < nq) {
-            const double VT = mfma4(V[k], eye, 0.0);             // V^T per quad: the A operand of C -= V W'
-#pragma unroll
-            for (int j = J0; j < GW; ++j) C[k][j] = mfma4(VT, W[j], C[k][j]);
-        }
-    }
+        for (int j = J0; j < GW; ++j) C[kk][j] = mfma4(VT, W[j], C[kk][j]);
+    });
 }
 
-// Panel J of group g (block 4 g + J): factor it in place, leave T and v's pivot entries in the panel's two auxiliary tiles, apply it to the
-// group's blocks right of it.  false: this was the last panel (fewer than four pivots: c sits in its block).
+// Panel J of group g (block 4 g + J; its pivot tile is kk = top): factor it in place, leave -T and the reflectors' pivot tile in the panel's
+// two auxiliary tiles, apply it to the group's blocks right of it.  false: this was the last panel (fewer than four pivots: c sits in its block).
 template <int J>
-__device__ __forceinline__ bool group_panel(double (&C)[GQ][GW], double *mine, int g, int nc, int nq, int si, int sb, int sj, double eye, GStamps &ST) {
-    const int p = GW * g + J, steps = nc - 4 * p < 4 ? nc - 4 * p : 4, q0 = p >> 2, bp = p & 3;
+__device__ __forceinline__ bool group_panel(double (&C)[GQ][GW], double *mine, int g, int nc, int top, int si, int sb, int sj, double eye, GStamps &ST) {
+    const int p = GW * g + J, steps = nc - 4 * p < 4 ? nc - 4 * p : 4;
     if (steps <= 0) return false;
-    double xm[GQ], vp[4] = {0.0, 0.0, 0.0, 0.0}, Tr[4] = {0.0, 0.0, 0.0, 0.0};
+    double vp[4] = {0.0, 0.0, 0.0, 0.0}, Tr[4] = {0.0, 0.0, 0.0, 0.0};
     double PT = 0.0;
 #pragma unroll
-    for (int k = 0; k < GQ; ++k)
-        if (k == q0) PT = C[k][J];
-    gpanel_step<0, J>(C, PT, xm, vp, Tr, q0, nq, bp, si, sb, sj);
-    if (steps > 1) gpanel_step<1, J>(C, PT, xm, vp, Tr, q0, nq, bp, si, sb, sj);
-    if (steps > 2) gpanel_step<2, J>(C, PT, xm, vp, Tr, q0, nq, bp, si, sb, sj);
-    if (steps > 3) gpanel_step<3, J>(C, PT, xm, vp, Tr, q0, nq, bp, si, sb, sj);
+    for (int k = 0; k < GQ; ++k) PT = k == top ? C[k][J] : PT;
+    gpanel_step<0, J>(C, PT, vp, Tr, top, J, si, sb, sj);
+    if (steps > 1) gpanel_step<1, J>(C, PT, vp, Tr, top, J, si, sb, sj);
+    if (steps > 2) gpanel_step<2, J>(C, PT, vp, Tr, top, J, si, sb, sj);
+    if (steps > 3) gpanel_step<3, J>(C, PT, vp, Tr, top, J, si, sb, sj);
 #pragma unroll
-    for (int k = 0; k < GQ; ++k)
-        if (k == q0) C[k][J] = PT;
+    for (int k = 0; k < GQ; ++k) C[k][J] = k == top ? PT : C[k][J];
     NIN_GST(ST, 3);
     if (steps < 4) return false;
     const double Ts = -(sj == 0 ? Tr[0] : sj == 1 ? Tr[1] : sj == 2 ? Tr[2] : Tr[3]);
     const double vdiag = sj == 0 ? vp[0] : sj == 1 ? vp[1] : sj == 2 ? vp[2] : vp[3];
+    const double vpiv = pivot_tile_v(PT, vdiag, J, si, sb, sj);
     mine[(GQ * GCB + 2 * p) << 6] = Ts;
-    mine[(GQ * GCB + 2 * p + 1) << 6] = vdiag;
+    mine[(GQ * GCB + 2 * p + 1) << 6] = vpiv;
     if constexpr (J + 1 < GW) {
         double V[GQ];
 #pragma unroll
-        for (int k = 0; k < GQ; ++k) V[k] = k == q0 ? pivot_tile_v(PT, vdiag, bp, si, sb, sj) : C[k][J];
-        group_apply<J + 1>(V, Ts, C, q0, nq, eye);
+        for (int k = 0; k < GQ; ++k) V[k] = k == top ? vpiv : C[k][J];
+        group_apply<J + 1>(V, Ts, C, top, eye);
     }
     NIN_GST(ST, 4);
     return true;
 }
 
+// the tiles of panel p's reflectors -> V: tile kk < top from the panel's block, the pivot tile (kk = top) from its auxiliary tile
+__device__ __forceinline__ void load_reflectors(const double *mine, int p, int top, double (&V)[GQ]) {
+    const double *const blk = mine + ((p * GQ) << 6), *const piv = mine + ((GQ * GCB + 2 * p + 1) << 6);
+    for_tiles_down(top, [&](auto t) __attribute__((always_inline)) {
+        constexpr int kk = decltype(t)::value;
+        V[kk] = *(kk == top ? piv : blk + (kk << 6));
+    });
+}
+
 // Factor the nrows x (nc + 1) problem held in the slot (c at column nc), solve R y = Q^T c: y -> yb (LDS), returns r . r.
 // LEFT-LOOKING by groups of four column blocks: a group's 4 x nq tiles are read once, take the reflectors of every panel left of the group
-// (read back from where the panels were factored: V below R in the panel's own tiles, T and v's pivot entries in two auxiliary tiles per
-// panel), are factored -- four panels, each applied to the blocks right of it in the registers -- and written once.  Nothing but finished
-// panels is ever re-read: per node ~0.6 MB of traffic against 2.5 MB of the right-looking form a panel at a time, and no load waits for a
-// store.
+// (read back from where the panels were factored: V below R in the panel's own tiles; -T and the reflectors' pivot tile in two auxiliary
+// tiles per panel), are factored -- four panels, each applied to the blocks right of it in the registers -- and written once.  Nothing but
+// finished panels is ever re-read: per node ~0.6 MB of traffic against 2.5 MB of the right-looking form a panel at a time, and no load
+// waits for a store.
 __device__ __forceinline__ double mfg_factor_solve(double *__restrict__ slot, int nc, int nrows, int lane, double *yb, GStamps &ST) {
     const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3, rowbase = 4 * sb + si;
     const double eye = si == sj ? 1.0 : 0.0;
-    const int n_panels = (nc + 3) >> 2, nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2, n_groups = (ncb + GW - 1) / GW;
+    const int nq = (nrows + 15) >> 4, ncb = (nc + 4) >> 2, n_groups = (ncb + GW - 1) / GW;
     double *const mine = slot + lane;
     for (int g = 0; g < n_groups; ++g) {
         double C[GQ][GW];
         double *const gp = mine + ((GW * g * GQ) << 6);
+        for_tiles_down(nq - 1, [&](auto t) __attribute__((always_inline)) {
+            constexpr int kk = decltype(t)::value;
 #pragma unroll
-        for (int j = 0; j < GW; ++j) {
-#pragma unroll
-            for (int k = 0; k < GQ; ++k)
-                if (k < nq) C[k][j] = gp[(j * GQ + k) << 6];     // (blocks beyond the node's: zero-filled by the caller)
-        }
+            for (int j = 0; j < GW; ++j) C[kk][j] = gp[(j * GQ + kk) << 6];   // (blocks beyond the node's: zero-filled by the caller)
+        });
         NIN_GST(ST, 1);
-        // the panels left of the group (every one of them has four reflectors); panel p + 1's tiles are on their way while panel p is applied
-        // (they are final: no store of this loop touches them)
-        double Vn[GQ], Tsn = 0.0, vdn = 0.0;
-#pragma unroll
-        for (int k = 0; k < GQ; ++k) Vn[k] = 0.0;
+        // the panels left of the group (every one of them has four reflectors), two per round: while one is applied the next one's tiles
+        // are on their way (they are final: no store of this loop touches them)
+        double VA[GQ], VB[GQ], TsA = 0.0, TsB = 0.0;
         if (g > 0) {
-#pragma unroll
-            for (int k = 0; k < GQ; ++k)
-                if (k < nq) Vn[k] = mine[k << 6];
-            Tsn = mine[(GQ * GCB) << 6];
-            vdn = mine[(GQ * GCB + 1) << 6];
+            load_reflectors(mine, 0, nq - 1, VA);
+            TsA = mine[(GQ * GCB) << 6];
         }
-        for (int p = 0; p < GW * g; ++p) {
-            const int q0 = p >> 2, bp = p & 3;
-            double V[GQ];
-#pragma unroll
-            for (int k = 0; k < GQ; ++k) V[k] = k == q0 ? pivot_tile_v(Vn[k], vdn, bp, si, sb, sj) : Vn[k];
-            const double Ts = Tsn;
-            if (p + 1 < GW * g) {
-                const int q1 = (p + 1) >> 2;
-                const double *const vnext = mine + (((p + 1) * GQ) << 6);
-#pragma unroll
-                for (int k = 0; k < GQ; ++k)
-                    if (k >= q1 && k < nq) Vn[k] = vnext[k << 6];
-                Tsn = mine[(GQ * GCB + 2 * (p + 1)) << 6];
-                vdn = mine[(GQ * GCB + 2 * (p + 1) + 1) << 6];
+        for (int p = 0; p < GW * g; p += 2) {                    // (GW * g is even)
+            load_reflectors(mine, p + 1, nq - 1 - ((p + 1) >> 2), VB);
+            TsB = mine[(GQ * GCB + 2 * (p + 1)) << 6];
+            group_apply<0>(VA, TsA, C, nq - 1 - (p >> 2), eye);
+            if (p + 2 < GW * g) {
+                load_reflectors(mine, p + 2, nq - 1 - ((p + 2) >> 2), VA);
+                TsA = mine[(GQ * GCB + 2 * (p + 2)) << 6];
             }
-            group_apply<0>(V, Ts, C, q0, nq, eye);
+            group_apply<0>(VB, TsB, C, nq - 1 - ((p + 1) >> 2), eye);
         }
         NIN_GST(ST, 2);
         // the group's own panels
-        if constexpr (GW == 4) {
-            if (group_panel<0>(C, mine, g, nc, nq, si, sb, sj, eye, ST))
-                if (group_panel<1>(C, mine, g, nc, nq, si, sb, sj, eye, ST))
-                    if (group_panel<2>(C, mine, g, nc, nq, si, sb, sj, eye, ST)) (void)group_panel<GW - 1>(C, mine, g, nc, nq, si, sb, sj, eye, ST);
-        } else if constexpr (GW == 2) {
-            if (group_panel<0>(C, mine, g, nc, nq, si, sb, sj, eye, ST)) (void)group_panel<GW - 1>(C, mine, g, nc, nq, si, sb, sj, eye, ST);
-        } else {
-            (void)group_panel<0>(C, mine, g, nc, nq, si, sb, sj, eye, ST);
-        }
+        const int top = nq - 1 - g;
+        if (group_panel<0>(C, mine, g, nc, top, si, sb, sj, eye, ST))
+            if (group_panel<1>(C, mine, g, nc, top, si, sb, sj, eye, ST))
+                if (group_panel<2>(C, mine, g, nc, top, si, sb, sj, eye, ST)) (void)group_panel<3>(C, mine, g, nc, top, si, sb, sj, eye, ST);
         NIN_GST(ST, 3);
+        for_tiles_down(nq - 1, [&](auto t) __attribute__((always_inline)) {
+            constexpr int kk = decltype(t)::value;
 #pragma unroll
-        for (int j = 0; j < GW; ++j) {
-#pragma unroll
-            for (int k = 0; k < GQ; ++k)
-                if (k < nq) gp[(j * GQ + k) << 6] = C[k][j];
-        }
+            for (int j = 0; j < GW; ++j) gp[(j * GQ + kk) << 6] = C[kk][j];
+        });
     }
     // c sits in block nc >> 2, column nc & 3
     const int cbc = nc >> 2, jc = nc & 3;
-    double *const cc = mine + ((cbc * GQ) << 6);
+    double *const cc = mine + ((cbc * GQ + nq - 1) << 6);        // (row tile q from the top: cc[-(q << 6)])
     NIN_GST(ST, 1);
     double rr = 0.0;
     {
         double t = 0.0;
         for (int q = 0; q < nq; ++q) {
-            const double x = cc[q << 6];
+            const double x = cc[-(q << 6)];
             const double xr = (16 * q + rowbase >= nc && sj == jc) ? x : 0.0;
             t = fma(xr, xr, t);
         }
         rr = wave_allsum(t);
     }
-    // ---- R y = (Q^T c)(0 : nc), block column by block column from the last: b[k] = this lane's ROW of the right-hand side in tile k ----
+    // ---- R y = (Q^T c)(0 : nc), block column by block column from the last: b[k] = this lane's ROW of the right-hand side in row tile k
+    //      (from the top) ----
     constexpr int BQ = (kMfgMaxDense * 3 + 15) / 16;           // row tiles that hold pivot rows
     double b[BQ];
 #pragma unroll
     for (int k = 0; k < BQ; ++k) {
         b[k] = 0.0;
-        if (16 * k < nc) b[k] = __shfl(cc[k << 6], (lane & ~3) | jc);
+        if (16 * k < nc) b[k] = __shfl(cc[-(k << 6)], (lane & ~3) | jc);
     }
     double Tn[BQ];                                               // the tiles of the next block column: on their way while this one is solved
 #pragma unroll
     for (int k = 0; k < BQ; ++k) {
         Tn[k] = 0.0;
-        if (k <= ((nc - 1) >> 4)) Tn[k] = mine[((((nc - 1) >> 2) * GQ + k) << 6)];
+        if (k <= ((nc - 1) >> 4)) Tn[k] = mine[((((nc - 1) >> 2) * GQ + nq - 1 - k) << 6)];
     }
     for (int cb = (nc - 1) >> 2; cb >= 0; --cb) {
         const int q = cb >> 2, quad = cb & 3, live = nc - 4 * cb < 4 ? nc - 4 * cb : 4;   // (a last block shares its columns with c)
@@ -277,18 +287,18 @@ __device__ __forceinline__ double mfg_factor_solve(double *__restrict__ slot, in
             bq = k == q ? b[k] : bq;
         }
         if (cb > 0) {
-            const double *const cn = mine + (((cb - 1) * GQ) << 6);
+            const double *const cn = mine + (((cb - 1) * GQ + nq - 1) << 6);
 #pragma unroll
             for (int k = 0; k < BQ; ++k)
-                if (k <= ((cb - 1) >> 2)) Tn[k] = cn[k << 6];
+                if (k <= ((cb - 1) >> 2)) Tn[k] = cn[-(k << 6)];
         }
         double y[4];
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
-            double s = __shfl(bq, 16 * i + 4 * quad);
+            double s = rl64(bq, 16 * i + 4 * quad);               // (wave-uniform lanes: v_readlane, the block's entries as scalars)
 #pragma unroll
-            for (int j = 3; j > i; --j) s = fma(-__shfl(Dt, 16 * i + 4 * quad + j), y[j], s);
-            const double yi = s * fast_rcp(__shfl(Dt, 16 * i + 4 * quad + i));
+            for (int j = 3; j > i; --j) s = fma(-rl64(Dt, 16 * i + 4 * quad + j), y[j], s);
+            const double yi = s * fast_rcp(rl64(Dt, 16 * i + 4 * quad + i));
             y[i] = i < live ? yi : 0.0;
         }
         if (lane < live) yb[4 * cb + lane] = lane == 0 ? y[0] : lane == 1 ? y[1] : lane == 2 ? y[2] : y[3];
@@ -413,10 +423,10 @@ __global__ __launch_bounds__(64, NIN_MFG_WAVES) void nin_gls_mfg_kernel(GridView
 #pragma unroll
                     for (int r = 0; r < 7; ++r) {
                         const int row = 7 * f + r;
-                        if (jq == 0) slot[tile_index(row, nc)] = B[3 + r][0];
+                        if (jq == 0) slot[tile_index(row, nc, nq)] = B[3 + r][0];
                         else {
 #pragma unroll
-                            for (int t = 0; t < 3; ++t) slot[tile_index(row, 3 * (int)myslot + t)] = B[3 + r][t];
+                            for (int t = 0; t < 3; ++t) slot[tile_index(row, 3 * (int)myslot + t, nq)] = B[3 + r][t];
                         }
                     }
                 }
@@ -433,8 +443,8 @@ __global__ __launch_bounds__(64, NIN_MFG_WAVES) void nin_gls_mfg_kernel(GridView
             if (lane < D) {
                 const int row = 7 * F + lane;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) slot[tile_index(row, 3 * lane + t)] = dod[t];
-                slot[tile_index(row, nc)] = 1.0;
+                for (int t = 0; t < 3; ++t) slot[tile_index(row, 3 * lane + t, nq)] = dod[t];
+                slot[tile_index(row, nc, nq)] = 1.0;
             }
         }
         if (lane < nfree) {
@@ -458,12 +468,12 @@ __global__ __launch_bounds__(64, NIN_MFG_WAVES) void nin_gls_mfg_kernel(GridView
             const int row = 7 * F + D + 3 * lane;
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                slot[tile_index(row + 0, 3 * sa + t)] = -(Ka[t * 3 + 0] * N0 + Ka[t * 3 + 1] * N1 + Ka[t * 3 + 2] * N2);
-                slot[tile_index(row + 0, 3 * sbb + t)] = Kb[t * 3 + 0] * N0 + Kb[t * 3 + 1] * N1 + Kb[t * 3 + 2] * N2;
-                slot[tile_index(row + 1, 3 * sa + t)] = -Tv[t];
-                slot[tile_index(row + 1, 3 * sbb + t)] = Tv[t];
-                slot[tile_index(row + 2, 3 * sa + t)] = -Uv[t];
-                slot[tile_index(row + 2, 3 * sbb + t)] = Uv[t];
+                slot[tile_index(row + 0, 3 * sa + t, nq)] = -(Ka[t * 3 + 0] * N0 + Ka[t * 3 + 1] * N1 + Ka[t * 3 + 2] * N2);
+                slot[tile_index(row + 0, 3 * sbb + t, nq)] = Kb[t * 3 + 0] * N0 + Kb[t * 3 + 1] * N1 + Kb[t * 3 + 2] * N2;
+                slot[tile_index(row + 1, 3 * sa + t, nq)] = -Tv[t];
+                slot[tile_index(row + 1, 3 * sbb + t, nq)] = Tv[t];
+                slot[tile_index(row + 2, 3 * sa + t, nq)] = -Uv[t];
+                slot[tile_index(row + 2, 3 * sbb + t, nq)] = Uv[t];
             }
         }
         wave_global_sync();

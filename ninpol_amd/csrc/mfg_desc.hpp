@@ -25,7 +25,7 @@ constexpr int kMfgMaxRows = 256, kMfgMaxCells = 64, kMfgMaxFaces = 127;
 constexpr int kMfgW0 = 1, kMfgW1 = 33, kMfgSlotTable = 65, kMfgFree0 = 75;
 constexpr int kMfgRowTiles = 16, kMfgColBlocks = 32;                   // tiles of 16 rows x 4 columns: 256 x 128
 constexpr int kMfgSlotDoubles = (kMfgRowTiles * kMfgColBlocks + 2 * kMfgColBlocks) * 64;   // one node's tiles + two auxiliary tiles per panel: 288 KB of global scratch
-constexpr int kMfgResidentWaves = 2 * 4 * 256;                         // slots at most: two wavefronts per SIMD (0.5 GB)
+constexpr int kMfgResidentWaves = 4 * 256;                             // slots at most: one wavefront per SIMD (288 MB)
 
 #ifdef __HIPCC__
 // 0: not for this kernel; 1: the words are filled.  Interior nodes only (a boundary face at the node: 0).

@@ -448,6 +448,48 @@ def test_gpu_wide_multifrontal_kernel_on_unstructured_tetrahedra(oracle_lib, mon
     assert plans["NIN_GLS_MFX_NO_BOUNDARY"]["mfx"] == plans["default"]["mfx"]
 
 
+@pytest.mark.parametrize("perm", ["ALH", "FAN"])
+def test_gpu_tiles_in_global_memory_kernel_on_a_random_cloud(oracle_lib, monkeypatch, perm):
+    """The Delaunay mesh of a random point cloud: a few per cent of its interior nodes have more cells than the wide kernel's 16 fronts +
+    21 dense cells (up to 60 cells here).  kernels_gls_mfg.hip takes them -- up to 32 fronts + 40 dense cells, the tiles of the dense
+    problem in a global-memory slot, left-looking panels -- where the block / global-scratch kernels ran before (NIN_GLS_NO_MFG: that
+    route).  Both routes against the oracle, row-scaled and element by element; through the full launch, an explicit target list (the
+    descriptors are made per call there) and the pieces of interpolate()'s pipeline."""
+    mesh = M.delaunay_tet_mesh(10, seed=4, lattice="random")
+    M.attach_fields(mesh, "u", perm=perm, neumann_plane=(0, 1.0), seed=3)
+    o = oracle_lib.OracleInterpolator("port", threads=8)
+    o.load_mesh(mesh)
+    wo, no = o.prepare("gls", "u")
+    Wo, _ = o.interpolate("u", "gls")
+    plans = {}
+    for route in ("default", "NIN_GLS_NO_MFG"):
+        with monkeypatch.context() as mp:
+            if route != "default":
+                mp.setenv(route, "1")
+            mp.setenv("NIN_E2E_MIN_NODES", "256")
+            I = _interp()
+            I.load_mesh(mesh_obj=mesh)
+            P = I.grid.n_points
+            w, nw = I.prepare_interpolator("gls", "u", np.arange(P))
+            plans[route] = I.grid.gls_plan()
+            assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL and util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL, route
+            assert util.elementwise_err(w, wo) <= util.elementwise_rtol("gls", perm), route
+            targets = np.arange(1, P, 3)
+            wt, nwt = I.prepare_interpolator("gls", "u", targets)
+            assert np.array_equal(wt, w[targets]) and np.array_equal(nwt, nw[targets]), route
+            W, _ = I.interpolate("u", "gls")                     # (the pipeline: sub-ranges of every list)
+            assert util.csr_rowscaled_err(W, Wo.indptr, Wo.indices, Wo.data) <= util.WEIGHT_RTOL, route
+    ne = np.diff(np.asarray(I.grid.esup_ptr))
+    interior = ~np.asarray(I.grid.boundary_points).astype(bool)
+    d, b = plans["default"], plans["NIN_GLS_NO_MFG"]
+    assert d["mfg_tiles"] >= int(np.sum(interior & (ne > 37))) > 20 and b["mfg_tiles"] == 0, (d, b)
+    assert d["mfx"] == b["mfx"]
+    heavy = ("block4", "block8", "scratch")
+    assert sum(b[k] for k in heavy) == sum(d[k] for k in heavy) + d["mfg_tiles"]
+    # every interior node of the cloud is on a one-wavefront multifrontal kernel now
+    assert d["mfx"] + d["mfg_tiles"] + d["mfw_large"] + d["mfw_small"] + d["mfw_general"] + d["hex8"] >= int(interior.sum()) - int(np.sum(interior & (ne <= 12)))
+
+
 def test_gpu_wide_kernel_dense_phase_alone():
     """mfx_strips.hpp's xstrip_factor -- the blocked Householder QR in register tiles behind the wide kernel -- on random
     problems of every size class against a host QR (tools/test_xstrip.hip, compiled by __graft_entry__.build())."""
