@@ -58,7 +58,7 @@ ALG_FLOPS = {"cube": 15869.0}
 
 PLAN_KERNEL_NAMES = {   # kernel of the launch plan -> its name in a rocprofv3 trace
     "block1": "nin_gls_block_kernel<1, *>", "block2": "nin_gls_block_kernel<2, *>", "block4": "nin_gls_block_kernel<4, *>",
-    "block8": "nin_gls_block_kernel<8, *>", "scratch": "nin_gls_wave_kernel", "hex8": "nin_gls_hex8w2_kernel",
+    "block8": "nin_gls_block_kernel<8, *>", "scratch": "nin_gls_team_kernel", "hex8": "nin_gls_hex8w2_kernel",
     "mfw_large": "nin_gls_mfw_kernel<12, 12, true, false, true>", "mfw_small": "nin_gls_mfw_kernel<6, 6, true, false, false>",
     "mfw_general": "nin_gls_mfw_kernel<12, 15, true, true, false>", "small4": "nin_gls_small_kernel<4>",
     "small8": "nin_gls_small_kernel<8>", "small12": "nin_gls_small_kernel<12>", "quad4": "nin_gls_quad4_kernel", "mfx_6x10": "nin_gls_mfx_kernel<6, 10, false>", "mfx_7x11": "nin_gls_mfx_kernel<7, 11, false>",
@@ -606,7 +606,11 @@ def main():
                         ("kuhn tets 40^3", lambda: M.tet_mesh(40, jitter=0.1), ("gls",)),
                         # round 4: UNSTRUCTURED tetrahedra, the mesh class of the reference's tetra numbers (performance.yaml:184-246):
                         # the Delaunay tetrahedrisation of a jittered body-centred cloud, ~2 M cells, 14 .. 40 cells around a node
-                        ("unstructured tets (Delaunay of a jittered 54^3 body-centred cloud)", lambda: M.delaunay_tet_mesh(54, seed=0), ("gls",))):
+                        ("unstructured tets (Delaunay of a jittered 54^3 body-centred cloud)", lambda: M.delaunay_tet_mesh(54, seed=0), ("gls",)),
+                        # ... and of a uniformly RANDOM cloud (what scipy.spatial.Delaunay of random points gives: up to ~60 cells around a
+                        # node, 7 % of the interior nodes beyond the wide kernel's 16 + 21 cells -> kernels_gls_mfg.hip, tiles in global memory)
+                        ("unstructured tets (Delaunay of a uniformly random cloud, as many points as a 40^3 body-centred one)",
+                         lambda: M.delaunay_tet_mesh(40, seed=0, lattice="random"), ("gls",))):
                     mo = make()
                     M.attach_fields(mo, "u", perm="ALH")
                     Io = ninpol_amd.Interpolator(device=local_rank, grid_build="device")
@@ -618,7 +622,7 @@ def main():
                     n_int = int((~np.asarray(Io.grid.boundary_points).astype(bool)).sum())
                     pl = Io.grid.gls_plan()
                     row["interior_nodes_off_the_block_kernel"] = round(
-                        (pl["hex8"] + pl["mfw_large"] + pl["mfw_small"] + pl["mfw_general"] + pl["mfx"]) / max(n_int, 1), 4)   # (pl["mfx"]: interior classes only)
+                        (pl["hex8"] + pl["mfw_large"] + pl["mfw_small"] + pl["mfw_general"] + pl["mfx"] + pl["mfg_tiles"]) / max(n_int, 1), 4)   # (pl["mfx"]: interior classes only)
                     rows[name] = row
                     del Io, mo
                     torch.cuda.empty_cache()

@@ -614,7 +614,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
     d.gls_too_large = rows_max[kGlsClasses - 1] > 1024;
     if ((rc = dev_alloc(d, &d.gls_queue, (size_t)kGlsQueueInts))) return rc;
     if (d.gls[kGlsClasses - 1].count) {
-        d.gls_scratch_slots = 1024;
+        d.gls_scratch_slots = std::min<int32_t>(d.gls[kGlsClasses - 1].count, 512);   // one per resident team (kernels_gls.hip)
         d.gls_scratch_stride = need_max[kGlsClasses - 1] / 8;
         if ((rc = dev_alloc(d, &d.gls_scratch, (size_t)d.gls_scratch_slots * d.gls_scratch_stride))) return rc;
     }

@@ -1,6 +1,6 @@
-// kernels_gls.hip -- GLS weights, gfx950: one node per wavefront, the system in a global-memory scratch slot.
-// This is the fallback for nodes whose system does not fit the LDS of one CU (more than ~85 cells around a
-// node); everything else runs in kernels_gls_block.hip (LDS) or kernels_gls_hex8mf.hip (registers).
+// kernels_gls.hip -- GLS weights, gfx950: the fallback for nodes no other kernel takes (more cells than kernels_gls_mfg.hip's 64, a
+// system that does not fit the LDS of one CU: a handful of nodes of a large unstructured mesh, none of a structured one): one node per
+// WORKGROUP of 8 or 16 wavefronts, the dense system in a global-memory scratch slot.
 //
 // What the reference does per node (gls.pyx:161-219): assemble the dense m x n system
 //   M = [ d_i^T on block i | 1 ]        n_elem rows    (x_K - x_v, gls.pyx:269-281)
@@ -16,12 +16,12 @@
 // one QR, no right-hand sides, one back-application of Q.  Zero rows (the empty row triples the
 // reference leaves for boundary faces) are dropped: they change nothing in a Householder QR.
 //
-// Mapping: rows across the 64 lanes (row r lives in lane r%64, slot r/64), columns walked by the
-// wave, the matrix column-major in LDS so a column is a conflict-free ds_read_b64 stripe; the
-// reflector v_k stays in registers while it is applied; dot products are DPP row reductions plus
-// four readlanes.  Nodes are pre-binned by system size (device_grid.hpp) so each launch has one LDS
-// budget and one rows-per-lane count.  Systems too large for LDS run the same code on a
-// global-memory slot per wave.
+// Mapping: rows across the 64 lanes (row r lives in lane r%64, slot r/64), the matrix column-major.  EVERY wavefront of the team reads
+// the pivot column and forms the reflector (the same arithmetic on the same words: the same bits), then takes every TW-th group of four
+// trailing columns -- the reflector stays in registers while it is applied, dot products are DPP row reductions plus four readlanes --,
+// one workgroup barrier per reflector.  (Until round 4 one WAVEFRONT ran a node alone: a 66-cell node -- 363 x 199 -- took 12.4 ms,
+// the long pole of a whole 2 M-cell launch; the team takes ~1 ms.)  Nodes are pre-binned by system size (device_grid.hpp) so each
+// launch has one rows-per-lane count.
 #include <hip/hip_runtime.h>
 
 #include "device_grid.hpp"
@@ -72,20 +72,17 @@ __device__ __forceinline__ int ufirst(int v) { return __builtin_amdgcn_readfirst
 
 constexpr int JB = 4;  // columns updated together (independent reductions in flight)
 
-template <int RPL, bool LDS>
-__global__ __launch_bounds__(256) void nin_gls_wave_kernel(GridView g, const int32_t *__restrict__ nodes,
-                                                           int32_t count, int add_neumann,
-                                                           double *__restrict__ out, double *__restrict__ nws,
-                                                           int32_t wave_doubles, double *scratch,
-                                                           long long scratch_stride) {
-    extern __shared__ double smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int wpb = blockDim.x >> 6;
-    double *base = LDS ? (smem + (size_t)wave * wave_doubles)
-                       : (scratch + (size_t)(blockIdx.x * wpb + wave) * scratch_stride);
+template <int RPL, int TW>
+__global__ __launch_bounds__(64 * TW) void nin_gls_team_kernel(GridView g, const int32_t *__restrict__ nodes, int32_t count, int add_neumann,
+                                                              double *__restrict__ out, double *__restrict__ nws, double *scratch,
+                                                              long long scratch_stride) {
+    constexpr bool LDS = false;
+    const int tid = threadIdx.x, nthr = 64 * TW;
+    const int lane = tid & 63;
+    const int wave = ufirst(tid >> 6);
+    double *base = scratch + (size_t)blockIdx.x * scratch_stride;
 
-    for (int32_t idx = blockIdx.x * wpb + wave; idx < count; idx += gridDim.x * wpb) {
+    for (int32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
         const int32_t p = ufirst(nodes ? nodes[idx] : idx);
         const int32_t eb = ufirst(g.esup_ptr[p]), ne = ufirst(g.esup_ptr[p + 1]) - eb;
         const int32_t fb = ufirst(g.fsup_ptr[p]), nf = ufirst(g.fsup_ptr[p + 1]) - fb;
@@ -106,8 +103,8 @@ __global__ __launch_bounds__(256) void nin_gls_wave_kernel(GridView g, const int
         // dgels returns an all-zero row n-1), or fewer rows than unknowns next to the node value: zero row -- the
         // same rule as kernels_gls_block.hip, so a node gets the same answer whichever kernel its size class runs on.
         if (((fl & 1) && !is_neu) || n_if == 0 || m < n - 1) {
-            for (int i = lane; i < ne; i += 64) out[eb + i] = 0.0;
-            if (lane == 0) nws[p] = 0.0;
+            for (int i = tid; i < ne; i += nthr) out[eb + i] = 0.0;
+            if (tid == 0) nws[p] = 0.0;
             continue;
         }
         const int ld = m;
@@ -115,9 +112,10 @@ __global__ __launch_bounds__(256) void nin_gls_wave_kernel(GridView g, const int
         double *tau = base + ((ne + 1) >> 1);                  // [n]
         double *A = tau + n;                                   // [ld * n] column-major
 
-        for (int i = lane; i < ne; i += 64) cells[i] = g.esup[eb + i];
-        for (int i = lane; i < ld * n; i += 64) A[i] = 0.0;
-        wave_sync<LDS>();
+        for (int i = tid; i < ne; i += nthr) cells[i] = g.esup[eb + i];
+        for (int i = tid; i < ld * n; i += nthr) A[i] = 0.0;
+        __syncthreads();
+        if (wave == 0) {   // assembly: one wavefront (a lane per cell / face: little work against the factorisation)
 
         const double xv0 = g.coords[3 * (size_t)p + 0], xv1 = g.coords[3 * (size_t)p + 1],
                      xv2 = g.coords[3 * (size_t)p + 2];
@@ -184,9 +182,12 @@ __global__ __launch_bounds__(256) void nin_gls_wave_kernel(GridView g, const int
             if_base += __popcll(mi);
             bf_base += __popcll(mb);
         }
-        wave_sync<LDS>();
+        }
+        __syncthreads();
 
-        // ---- Householder QR of the first n-1 columns, applied to the last one as it goes ----------
+        // ---- Householder QR of the first n-1 columns, applied to the last one as it goes: every wavefront forms reflector k from the
+        //      pivot column (nobody writes it during the step), wavefront w applies it to the column groups w, w + TW, ..; one barrier;
+        //      then wavefront 0 leaves v_k in the column for the back-application (R itself is never read again) ----------
         bool singular = false;
         for (int k = 0; k < n - 1; ++k) {
             double v[RPL];
@@ -208,15 +209,13 @@ __global__ __launch_bounds__(256) void nin_gls_wave_kernel(GridView g, const int
                 for (int c = 0; c < RPL; ++c) {
                     const int r = lane + 64 * c;
                     v[c] = r > k ? v[c] * sc : (r == k ? 1.0 : 0.0);
-                    if (r > k && r < m) A[r + (size_t)k * ld] = v[c];
-                    if (r == k) A[r + (size_t)k * ld] = beta;
                 }
             } else {
                 singular = singular || (alpha == 0.0);
             }
-            if (lane == 0) tau[k] = tk;
+            if (tid == 0) tau[k] = tk;
             if (tk != 0.0) {
-                for (int j0 = k + 1; j0 < n; j0 += JB) {
+                for (int j0 = k + 1 + JB * wave; j0 < n; j0 += JB * TW) {
                     double a[JB][RPL], s[JB];
 #pragma unroll
                     for (int jj = 0; jj < JB; ++jj) {
@@ -242,9 +241,17 @@ __global__ __launch_bounds__(256) void nin_gls_wave_kernel(GridView g, const int
                     }
                 }
             }
-            wave_sync<LDS>();
+            __syncthreads();
+            if (wave == 0 && tk != 0.0) {
+#pragma unroll
+                for (int c = 0; c < RPL; ++c) {
+                    const int r = lane + 64 * c;
+                    if (r > k && r < m) A[r + (size_t)k * ld] = v[c];
+                }
+            }
         }
-
+        __syncthreads();
+        if (wave == 0) {
         // ---- residual of the last column: r = Q [0; c~(n-1:m)], weights = r(0:ne) / (r.r) ----------
         double z[RPL];
         double rr = 0.0;
@@ -282,16 +289,19 @@ __global__ __launch_bounds__(256) void nin_gls_wave_kernel(GridView g, const int
         const double add = add_neumann ? nwv : 0.0;
         for (int i = lane; i < ne; i += 64) out[eb + i] = tau[i] + add;
         if (lane == 0) nws[p] = nwv;
-        wave_sync<LDS>();
+        }
+        __syncthreads();   // (the slot is the next node's)
     }
 }
 
 template <int RPL>
 int launch_rpl(const GridView &g, const int32_t *nodes, int32_t count, int add_neumann, double *out, double *nws,
                double *scratch, int64_t scratch_stride, int32_t scratch_slots, hipStream_t stream) {
-    const int64_t blocks = count < scratch_slots ? count : scratch_slots;   // one wave, one scratch slot per block
-    hipLaunchKernelGGL((nin_gls_wave_kernel<RPL, false>), dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, count,
-                       add_neumann, out, nws, 0, scratch, (long long)scratch_stride);
+    const int64_t blocks = count < scratch_slots ? count : scratch_slots;   // one team, one scratch slot per workgroup
+    constexpr int TW = (RPL == 4 || RPL == 8) ? 16 : 8;                    // (256 rows and more: ~100 columns and more, 25 column groups a step;
+                                                                           //  16 rows per lane: 160 registers, eight wavefronts)
+    hipLaunchKernelGGL((nin_gls_team_kernel<RPL, TW>), dim3((unsigned)blocks), dim3(64 * TW), 0, stream, g, nodes, count, add_neumann, out, nws,
+                       scratch, (long long)scratch_stride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -312,6 +322,6 @@ int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int
     return -5;  // more than 1024 rows in one node's system
 }
 
-const char *kernel_name_gls() { return "nin_gls_wave_kernel"; }
+const char *kernel_name_gls() { return "nin_gls_team_kernel"; }
 
 }  // namespace nin
