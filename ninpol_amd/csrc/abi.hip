@@ -773,8 +773,8 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
     if (!all && n_targets < 0) return fail(NIN_EINVAL, "negative n_targets");
     int rc = 0;
     if (all) {
-        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
-        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, dev_csr_data, dev_neumann_ws, stream);
+        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, d.nnz_e, dev_csr_data, dev_neumann_ws, stream);
+        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, nullptr, (int32_t)P, (int32_t)g->h.mx_elems_per_point, d.nnz_e, dev_csr_data, dev_neumann_ws, stream);
         else {
             HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
             const int only = gls_only();
@@ -858,8 +858,8 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         if (lists[c].empty()) continue;
         const int32_t *dl = dl0 + first[c];
         const int32_t cnt = (int32_t)lists[c].size();
-        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
-        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, dev_csr_data, dev_neumann_ws, stream);
+        if (method == NIN_METHOD_IDW) rc = launch_idw(d.v, dl, cnt, 0, 0, dev_csr_data, dev_neumann_ws, stream);
+        else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_hex8(d, dl, ddesc, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses + 8 + DeviceGrid::kMfxLists)
             rc = launch_gls_mfg(d.v, dl, dmfg, cnt, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue + 14, d.mfg_tiles, d.mfg_slots, stream);
@@ -1001,7 +1001,7 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
     const int32_t P = (int32_t)g->h.n_points;
     if (method != NIN_METHOD_GLS)
         return launch_rows_range(d.v, method == NIN_METHOD_LS ? 1 : 0, P, d.chunk_node[k], d.chunk_node[k + 1],
-                                 (int32_t)g->h.mx_elems_per_point, out, nws, stream);
+                                 (int32_t)g->h.mx_elems_per_point, d.nnz_e, out, nws, stream);
     HIP_TRY(hipMemsetAsync(d.gls_queue, 0, kGlsQueueInts * sizeof(int32_t), stream));   // the launches' work counters
     constexpr int lg = kGlsClasses + 8 + DeviceGrid::kMfxLists;   // kernels_gls_mfg.hip's list
     int rc = gls_side_begin(d, 1, out, nws, stream, d.chunk_off[kGlsClasses - 1][k],
@@ -1209,8 +1209,8 @@ int nin_apply_device(nin_grid *g, int method, const double *dev_u_cells, int32_t
     // Neumann flags only: the reference's callers do `weights.dot(u)` per field with the same matrix)
     int rc = nin_weights_device(g, method, nullptr, 0, 1, d.apply_weights, dev_neumann_ws, stream_);
     if (rc) return rc;
-    rc = n_fields == 1 ? launch_apply(d.v, d.apply_weights, dev_u_cells, dev_node_values, (int32_t)g->h.mx_elems_per_point, stream)
-                       : launch_apply_fields(d.v, d.apply_weights, dev_u_cells, n_fields, dev_node_values, (int32_t)g->h.mx_elems_per_point, stream);
+    rc = n_fields == 1 ? launch_apply(d.v, d.apply_weights, dev_u_cells, dev_node_values, (int32_t)g->h.mx_elems_per_point, d.nnz_e, stream)
+                       : launch_apply_fields(d.v, d.apply_weights, dev_u_cells, n_fields, dev_node_values, (int32_t)g->h.mx_elems_per_point, d.nnz_e, stream);
     if (rc) return fail(rc, "launch failed");
     return NIN_OK;
 }

@@ -15,12 +15,29 @@ namespace nin {
 
 namespace {
 
+// A wavefront owns 64 consecutive nodes; their rows are ONE contiguous run of `data`.  The lanes walk the run 64 entries at a time
+// (whole lines in), a ballot marks the entries that stay, and every lane counts the marks that fall into its own row.  (The first
+// version gave a lane its node's row: 64-byte lane strides on a hexahedron mesh, 200 bytes on tetrahedra -- 1.70 ms at 10 M cells.)
 __global__ __launch_bounds__(256) void nin_row_nnz_kernel(GridView g, const double *__restrict__ data,
-                                                          int32_t *__restrict__ row_nnz, int32_t p_begin, int32_t p_end) {
-    for (int32_t p = p_begin + blockIdx.x * blockDim.x + threadIdx.x; p < p_end; p += gridDim.x * blockDim.x) {
+                                                          int32_t *__restrict__ row_nnz, int32_t tile_begin, int32_t tile_end, int32_t p_end) {
+    const int lane = threadIdx.x & 63;
+    const int32_t wpb = blockDim.x >> 6;
+    for (int32_t tile = tile_begin + blockIdx.x * wpb + (threadIdx.x >> 6); tile < tile_end; tile += gridDim.x * wpb) {
+        const int32_t p0 = tile * 64, p = p0 + lane, pe = p0 + 64 < p_end ? p0 + 64 : p_end;
+        const int32_t run_b = g.esup_ptr[p0], run_e = g.esup_ptr[pe];
+        const bool live = p < p_end;
+        const int32_t b = live ? g.esup_ptr[p] : run_e, e = live ? g.esup_ptr[p + 1] : run_e;
         int32_t c = 0;
-        for (int32_t q = g.esup_ptr[p]; q < g.esup_ptr[p + 1]; ++q) c += (data[q] != 0.0);
-        row_nnz[p] = c;
+        for (int32_t i0 = run_b; i0 < run_e; i0 += 64) {
+            const int32_t i = i0 + lane;
+            const unsigned long long m = __ballot(i < run_e && data[i] != 0.0);   // what eliminate_zeros keeps: NaNs stay, +-0 go
+            const int32_t lo = (b > i0 ? b : i0) - i0, hi = (e < i0 + 64 ? e : i0 + 64) - i0;
+            if (hi > lo) {
+                const unsigned long long below_hi = hi >= 64 ? ~0ull : (1ull << hi) - 1ull;
+                c += __popcll(m & below_hi & ~((1ull << lo) - 1ull));
+            }
+        }
+        if (live) row_nnz[p] = c;
     }
 }
 
@@ -60,23 +77,24 @@ __global__ __launch_bounds__(256) void nin_compact_kernel(GridView g, const doub
 // row order; the 64 rows of a wavefront's nodes are one contiguous run of data / esup, copied HBM -> LDS cooperatively (whole
 // lines; a lane reading its own row straight from HBM strides 64 bytes: FETCH_SIZE 2.65 GB raw for 0.97 GB of rows, 0.84 ms at
 // 10 M cells), u is gathered (L2).  NF fields at once (u: [k][n_elems], values: [k][n_points]): the run is staged once.
-constexpr int kApplyCap = 1024;   // most entries of LDS a wavefront may own (12 KiB); a longer run goes straight from HBM
+constexpr int kApplyCap = 1024;   // most entries of LDS a wavefront may own (12 KiB) on a mesh whose 64 longest rows fit that; else
+constexpr int kApplyCapLong = 1536;   // ... 18 KiB and tiles of 64, 32 or 16 nodes (kernels_idw_ls.hip's rule); a longer run goes straight from HBM
 // `cap`: the entries of LDS each wavefront owns in THIS launch (64 x the longest row, at most kApplyCap: 6 KiB a wave on a
 // hexahedron mesh -- six workgroups per CU instead of three; the kernel lives on loads in flight: 0.56 -> 0.33 ms at 10 M cells)
 template <int NF>
 __global__ __launch_bounds__(256) void nin_apply_kernel(GridView g, const double *__restrict__ data,
                                                         const double *__restrict__ u, int32_t k0, int32_t k,
-                                                        double *__restrict__ values, int32_t cap) {
+                                                        double *__restrict__ values, int32_t cap, int32_t tn) {
     extern __shared__ double apply_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *const wl = apply_lds + (size_t)wave * cap;
     int32_t *const cl = reinterpret_cast<int32_t *>(apply_lds + 4 * (size_t)cap) + (size_t)wave * cap;
     const size_t E = (size_t)g.n_elems, P = (size_t)g.n_points;
-    const int32_t n_tiles = (g.n_points + 63) / 64;
+    const int32_t n_tiles = (g.n_points + tn - 1) / tn;
     for (int32_t tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
-        const int32_t p0 = tile * 64, p = p0 + lane, pe = p0 + 64 < g.n_points ? p0 + 64 : g.n_points;
+        const int32_t p0 = tile * tn, p = p0 + lane, pe = p0 + tn < g.n_points ? p0 + tn : g.n_points;
         const int32_t run_b = g.esup_ptr[p0], run_e = g.esup_ptr[pe], len = run_e - run_b;
-        const bool staged = len <= cap, live = p < g.n_points;
+        const bool staged = len <= cap, live = lane < tn && p < g.n_points;
         if (staged) {
             for (int32_t i = lane; i < len; i += 64) { wl[i] = data[run_b + i]; cl[i] = g.esup[run_b + i]; }
         }
@@ -153,7 +171,8 @@ int grid_for(int64_t n) {
 int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipStream_t stream, int32_t p_begin, int32_t p_end) {
     if (p_end < 0) p_end = g.n_points;
     if (p_end <= p_begin) return 0;
-    hipLaunchKernelGGL(nin_row_nnz_kernel, dim3(grid_for(p_end - p_begin)), dim3(256), 0, stream, g, data, row_nnz, p_begin, p_end);
+    hipLaunchKernelGGL(nin_row_nnz_kernel, dim3(grid_for(p_end - p_begin)), dim3(256), 0, stream, g, data, row_nnz, p_begin / 64,
+                       (int32_t)(((int64_t)p_end + 63) / 64), p_end);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -179,26 +198,40 @@ int launch_apply_list(const GridView &g, const double *data, const double *u, in
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// LDS entries per wavefront for rows of at most `mx_row` entries: 64 rows, in steps of 64, at most kApplyCap
-static int32_t apply_cap(int32_t mx_row) {
+// LDS entries per wavefront and nodes per tile for rows of at most `mx_row` entries, `nnz` in all: 64 rows in steps of 64, at most
+// kApplyCap; past that kApplyCapLong and as many nodes a tile as fit it at 1.25 x the mean row length
+static int32_t apply_cap(int32_t mx_row, int64_t nnz, int32_t n_points, int32_t *tn) {
     int64_t c = 64 * (int64_t)(mx_row > 0 ? mx_row : 1);
-    return (int32_t)(c > kApplyCap ? kApplyCap : c);
+    *tn = 64;
+    if (c <= kApplyCap) return (int32_t)c;
+    const double mean_row = nnz > 0 && n_points > 0 ? (double)nnz / (double)n_points : (double)mx_row;
+    while (*tn > 16 && *tn * mean_row * 1.25 > (double)kApplyCapLong) *tn >>= 1;
+    return kApplyCapLong;
 }
-int launch_apply(const GridView &g, const double *data, const double *u, double *values, int32_t mx_row, hipStream_t stream) {
-    const int32_t cap = apply_cap(mx_row);
-    hipLaunchKernelGGL(nin_apply_kernel<1>, dim3(grid_for(g.n_points)), dim3(256), (size_t)cap * 4 * 12, stream, g, data, u, 0, 1, values, cap);
+static int apply_grid(const GridView &g, int32_t tn) {
+    const int64_t blocks = ((int64_t)(g.n_points + tn - 1) / tn + 3) / 4;
+    return (int)(blocks < 1 ? 1 : blocks > 256 * 32 ? 256 * 32 : blocks);
+}
+int launch_apply(const GridView &g, const double *data, const double *u, double *values, int32_t mx_row, int64_t nnz, hipStream_t stream) {
+    int32_t tn;
+    const int32_t cap = apply_cap(mx_row, nnz, g.n_points, &tn);
+    if (allow_dynamic_lds<nin_apply_kernel<1>>((size_t)cap * 4 * 12)) return -3;
+    hipLaunchKernelGGL(nin_apply_kernel<1>, dim3(apply_grid(g, tn)), dim3(256), (size_t)cap * 4 * 12, stream, g, data, u, 0, 1, values, cap, tn);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 // k fields: four per pass over the weights (the rows of a wavefront are staged once per pass)
-int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values, int32_t mx_row,
+int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values, int32_t mx_row, int64_t nnz,
                         hipStream_t stream) {
-    const int32_t cap = apply_cap(mx_row);
+    int32_t tn;
+    const int32_t cap = apply_cap(mx_row, nnz, g.n_points, &tn);
     const size_t lds = (size_t)cap * 4 * 12;
+    const dim3 grid(apply_grid(g, tn));
+    if (allow_dynamic_lds<nin_apply_kernel<1>>(lds) || allow_dynamic_lds<nin_apply_kernel<2>>(lds) || allow_dynamic_lds<nin_apply_kernel<4>>(lds)) return -3;
     for (int32_t k0 = 0; k0 < k; k0 += 4) {
-        if (k - k0 >= 3) hipLaunchKernelGGL(nin_apply_kernel<4>, dim3(grid_for(g.n_points)), dim3(256), lds, stream, g, data, u, k0, k, values, cap);
-        else if (k - k0 == 2) hipLaunchKernelGGL(nin_apply_kernel<2>, dim3(grid_for(g.n_points)), dim3(256), lds, stream, g, data, u, k0, k, values, cap);
-        else hipLaunchKernelGGL(nin_apply_kernel<1>, dim3(grid_for(g.n_points)), dim3(256), lds, stream, g, data, u, k0, k, values, cap);
+        if (k - k0 >= 3) hipLaunchKernelGGL(nin_apply_kernel<4>, grid, dim3(256), lds, stream, g, data, u, k0, k, values, cap, tn);
+        else if (k - k0 == 2) hipLaunchKernelGGL(nin_apply_kernel<2>, grid, dim3(256), lds, stream, g, data, u, k0, k, values, cap, tn);
+        else hipLaunchKernelGGL(nin_apply_kernel<1>, grid, dim3(256), lds, stream, g, data, u, k0, k, values, cap, tn);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

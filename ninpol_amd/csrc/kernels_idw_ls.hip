@@ -4,7 +4,9 @@
 // HBM-bound (190 algorithmic bytes per node on structured hexahedra).  One lane owns one node
 // and walks its esup row in order, so the arithmetic is the reference's, operation for operation; what
 // the kernel is about is how the bytes move:
-//   * a wavefront owns 64 consecutive nodes, whose esup rows are ONE contiguous run of the CSR arrays.
+//   * a wavefront owns 64 consecutive nodes (32 or 16 where the rows are long: unstructured tetrahedra have ~25 cells around a
+//     node, and a tile's run must fit the wave's LDS -- the lane-by-lane path below it writes 8 bytes a lane at a row's stride:
+//     1.1 TB/s on a Delaunay mesh against 4.3 on hexahedra), whose esup rows are ONE contiguous run of the CSR arrays.
 //     The run of cell ids is copied HBM -> LDS cooperatively (lane l takes entries l, l + 64, ...:
 //     whole 256-byte lines), each lane then reads its own row from LDS;
 //   * the centroids are gathered per lane (irregular by nature; neighbouring nodes share most of their
@@ -150,19 +152,19 @@ __device__ __forceinline__ void ls_row(const GridView &g, int32_t p, const int32
 template <int METHOD>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void nin_rows_kernel(GridView g, int32_t n, int32_t cap,
                                                                       double *__restrict__ out, double *__restrict__ nws,
-                                                                      int32_t tile_begin, int32_t tile_end) {
+                                                                      int32_t tile_begin, int32_t tile_end, int32_t tn) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *wbuf = smem + (size_t)wave * cap + (size_t)wave * ((cap + 1) >> 1);   // [cap] weights
     int32_t *cbuf = reinterpret_cast<int32_t *>(wbuf + cap);                        // [cap] cell ids
-    // tiles [tile_begin, tile_end) of 64 nodes (all of them, or one chunk of the pipelined interpolate())
+    // tiles [tile_begin, tile_end) of tn = 64 / 32 / 16 nodes (all of them, or one chunk of the pipelined interpolate())
     for (int32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave; tile < tile_end; tile += gridDim.x * kWavesPerBlock) {
-        const int32_t p0 = tile * 64, p = p0 + lane;
-        const int32_t pe = p0 + 64 < n ? p0 + 64 : n;
+        const int32_t p0 = tile * tn, p = p0 + lane;
+        const int32_t pe = p0 + tn < n ? p0 + tn : n;
         const int32_t run_b = g.esup_ptr[p0], run_e = g.esup_ptr[pe];   // wave-uniform loads
         const int32_t len = run_e - run_b;
         const bool staged = len <= cap;
-        const bool live = p < n;
+        const bool live = lane < tn && p < n;
         int32_t b = 0, e = 0;
         bool skip = true;
         if (live) {
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void nin_rows_targets_kernel(GridView g, const
 }
 
 template <int METHOD>
-int launch_rows(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, double *out, double *nws,
+int launch_rows(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, int64_t nnz, double *out, double *nws,
                 hipStream_t stream, int32_t p_begin = 0, int32_t p_end = -1) {
     if (n_targets <= 0) return 0;
     if (targets) {
@@ -232,39 +234,47 @@ int launch_rows(const GridView &g, const int32_t *targets, int32_t n_targets, in
         hipLaunchKernelGGL((nin_rows_targets_kernel<METHOD>), dim3((unsigned)blocks), dim3(256), 0, stream, g, targets, n_targets, out, nws);
         return hipGetLastError() == hipSuccess ? 0 : -3;
     }
-    // LDS per wave: room for 64 rows of the longest length, capped at 12 KiB of weights + ids per wave
+    // LDS per wave: room for 64 rows of the longest length if that is at most 12 KiB of weights + ids (structured meshes); else 18 KiB
+    // and as many nodes a tile -- 64, 32 or 16 -- as fit it at 1.25 x the mesh's mean row length (a tile that is longer still takes
+    // the lane-by-lane path)
     int64_t cap = (int64_t)64 * (mx_row > 0 ? mx_row : 8);
-    if (cap > 1024) cap = 1024;
+    int32_t tn = 64;
+    if (cap > 1024) {
+        cap = 1536;
+        const double mean_row = nnz > 0 && n_targets > 0 ? (double)nnz / (double)n_targets : (double)mx_row;
+        while (tn > 16 && tn * mean_row * 1.25 > (double)cap) tn >>= 1;
+    }
     cap = (cap + 1) & ~(int64_t)1;
     const size_t dyn = (size_t)kWavesPerBlock * (cap * 8 + ((cap + 1) / 2) * 8);
     if (p_end < 0 || p_end > n_targets) p_end = n_targets;
-    const int32_t tile_begin = p_begin / 64, tile_end = (int32_t)(((int64_t)p_end + 63) / 64);   // (p_begin: a multiple of 64)
+    const int32_t tile_begin = p_begin / tn, tile_end = (int32_t)(((int64_t)p_end + tn - 1) / tn);   // (p_begin: a multiple of 64)
     const int64_t tiles = tile_end - tile_begin;
     if (tiles <= 0) return 0;
     int64_t blocks = (tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t cap_blocks = 256 * 8;
     if (blocks > cap_blocks) blocks = cap_blocks;
+    if (allow_dynamic_lds<nin_rows_kernel<METHOD>>(dyn)) return -3;
     hipLaunchKernelGGL((nin_rows_kernel<METHOD>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), dyn, stream, g, n_targets,
-                       (int32_t)cap, out, nws, tile_begin, tile_end);
+                       (int32_t)cap, out, nws, tile_begin, tile_end, tn);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 }  // namespace
 
-int launch_idw(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, double *out, double *nws,
+int launch_idw(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, int64_t nnz, double *out, double *nws,
                hipStream_t stream) {
-    return launch_rows<0>(g, targets, n_targets, mx_row, out, nws, stream);
+    return launch_rows<0>(g, targets, n_targets, mx_row, nnz, out, nws, stream);
 }
 
-int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, double *out, double *nws,
+int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, int64_t nnz, double *out, double *nws,
               hipStream_t stream) {
-    return launch_rows<1>(g, targets, n_targets, mx_row, out, nws, stream);
+    return launch_rows<1>(g, targets, n_targets, mx_row, nnz, out, nws, stream);
 }
 
-int launch_rows_range(const GridView &g, int method_ls, int32_t n_points, int32_t p_begin, int32_t p_end, int32_t mx_row,
+int launch_rows_range(const GridView &g, int method_ls, int32_t n_points, int32_t p_begin, int32_t p_end, int32_t mx_row, int64_t nnz,
                       double *out, double *nws, hipStream_t stream) {
-    return method_ls ? launch_rows<1>(g, nullptr, n_points, mx_row, out, nws, stream, p_begin, p_end)
-                     : launch_rows<0>(g, nullptr, n_points, mx_row, out, nws, stream, p_begin, p_end);
+    return method_ls ? launch_rows<1>(g, nullptr, n_points, mx_row, nnz, out, nws, stream, p_begin, p_end)
+                     : launch_rows<0>(g, nullptr, n_points, mx_row, nnz, out, nws, stream, p_begin, p_end);
 }
 
 }  // namespace nin

@@ -8,11 +8,29 @@
 
 namespace nin {
 
+#ifdef __HIPCC__
+// dynamic LDS beyond the default limit: the attribute belongs to the (kernel, device) pair; raised once per new maximum
+template <auto KERN>
+inline int allow_dynamic_lds(size_t bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    static size_t allowed[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t &a = allowed[dev & 63];
+    if (bytes > a) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -3;
+        a = bytes;
+    }
+    return 0;
+}
+#endif
+
 // all return 0 or a negative NIN_E* code; launches are asynchronous on `stream`
-// targets == nullptr: all nodes 0 .. n_targets-1 (the wave-cooperative kernel); mx_row = MX_ELEMENTS_PER_POINT
-int launch_idw(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, double *out, double *nws,
+// targets == nullptr: all nodes 0 .. n_targets-1 (the wave-cooperative kernel); mx_row = MX_ELEMENTS_PER_POINT, nnz = the length of esup
+// (the mean row length decides how many nodes make a tile)
+int launch_idw(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, int64_t nnz, double *out, double *nws,
                hipStream_t stream);
-int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, double *out, double *nws,
+int launch_ls(const GridView &g, const int32_t *targets, int32_t n_targets, int32_t mx_row, int64_t nnz, double *out, double *nws,
               hipStream_t stream);
 // one GLS size class: `nodes` lists the class members (device), lds_bytes is per wave
 int launch_gls_class(const GridView &g, const int32_t *nodes, int32_t count, int32_t lds_bytes,
@@ -71,15 +89,15 @@ int launch_row_nnz(const GridView &g, const double *data, int32_t *row_nnz, hipS
 int launch_compact(const GridView &g, const double *data, const int32_t *new_ptr, int32_t *indices,
                    double *vals, hipStream_t stream, int32_t p_begin = 0, int32_t p_end = -1);
 // IDW (method_ls = 0) / LS (1) weights of the nodes [p_begin, p_end) (p_begin: a multiple of 64)
-int launch_rows_range(const GridView &g, int method_ls, int32_t n_points, int32_t p_begin, int32_t p_end, int32_t mx_row,
+int launch_rows_range(const GridView &g, int method_ls, int32_t n_points, int32_t p_begin, int32_t p_end, int32_t mx_row, int64_t nnz,
                       double *out, double *nws, hipStream_t stream);
 
-int launch_apply(const GridView &g, const double *data, const double *u, double *values, int32_t mx_row, hipStream_t stream);
+int launch_apply(const GridView &g, const double *data, const double *u, double *values, int32_t mx_row, int64_t nnz, hipStream_t stream);
 // the same for the listed nodes only (one lane per node, rows straight from HBM)
 int launch_apply_list(const GridView &g, const double *data, const double *u, int32_t k, double *values, const int32_t *list,
                       int32_t count, hipStream_t stream);
 // k fields at once: u [k][n_elems], values [k][n_points]
-int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values, int32_t mx_row,
+int launch_apply_fields(const GridView &g, const double *data, const double *u, int32_t k, double *values, int32_t mx_row, int64_t nnz,
                         hipStream_t stream);
 
 // GLS launch plan (grid_device.hip): size class of every node (255 = the hex8 kernel, 254 / 253 / 252 = the one-wavefront multifrontal kernel: two-coloured nodes large / small, general kind) and, per class, the

@@ -1,12 +1,14 @@
 """End-to-end interpolate() (field upload -> weights -> device-side compaction -> PCIe -> scipy.sparse.csr_matrix) on the
-10 M-cell mesh, with a phase breakdown: `python tools/time_e2e.py [edge]`; NIN_TIMING=1 adds the native call's own laps."""
+10 M-cell mesh (or another), with a phase breakdown: `python tools/time_e2e.py [edge | del54 | delr40]`; NIN_TIMING=1 adds the native call's own laps."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import ninpol_amd
 from ninpol_amd import interpolator as NI
 from ninpol_amd import mesh as M
-m = M.hex_mesh(int(sys.argv[1]) if len(sys.argv) > 1 else 216, jitter=0.15); M.attach_fields(m, "u", perm="ALH")
+arg = sys.argv[1] if len(sys.argv) > 1 else "216"   # an edge of the hexahedron mesh, or del<n> / delr<n>: a Delaunay mesh
+m = (M.delaunay_tet_mesh(int(arg[4:]), seed=0, lattice="random") if arg.startswith("delr") else M.delaunay_tet_mesh(int(arg[3:]), seed=0)
+     if arg.startswith("del") else M.hex_mesh(int(arg), jitter=0.15)); M.attach_fields(m, "u", perm="ALH")
 I = ninpol_amd.Interpolator(grid_build="device"); I.load_mesh(mesh_obj=m)
 phases = {}
 def wrap(mod, name):
