@@ -63,7 +63,7 @@ PLAN_KERNEL_NAMES = {   # kernel of the launch plan -> its name in a rocprofv3 t
     "mfw_general": "nin_gls_mfw_kernel<12, 15, true, true, false>", "small4": "nin_gls_small_kernel<4>",
     "small8": "nin_gls_small_kernel<8>", "small12": "nin_gls_small_kernel<12>", "quad4": "nin_gls_quad4_kernel", "mfx_6x10": "nin_gls_mfx_kernel<6, 10, false>", "mfx_7x11": "nin_gls_mfx_kernel<7, 11, false>",
     "mfx_8x13": "nin_gls_mfx_kernel<8, 13, false>", "mfx_9x15": "nin_gls_mfx_kernel<9, 15, false>", "mfx_10x16": "nin_gls_mfx_kernel<10, 16, false>",
-    "mfx_boundary": "nin_gls_mfx_kernel<7, 11, true>", "mfg_tiles": "nin_gls_mfg_kernel"}
+    "mfx_boundary": "nin_gls_mfx_kernel<7, 11, true>", "mfg_tiles": "nin_gls_mfg_kernel", "mfx_4x7": "nin_gls_mfx_kernel<4, 7, false>"}
 
 
 def gls_kernel_rows(grid, launch, time_launches, reps=3):
@@ -610,7 +610,11 @@ def main():
                         # ... and of a uniformly RANDOM cloud (what scipy.spatial.Delaunay of random points gives: up to ~60 cells around a
                         # node, 7 % of the interior nodes beyond the wide kernel's 16 + 21 cells -> kernels_gls_mfg.hip, tiles in global memory)
                         ("unstructured tets (Delaunay of a uniformly random cloud, as many points as a 40^3 body-centred one)",
-                         lambda: M.delaunay_tet_mesh(40, seed=0, lattice="random"), ("gls",))):
+                         lambda: M.delaunay_tet_mesh(40, seed=0, lattice="random"), ("gls",)),
+                        # UNSTRUCTURED prisms (the reference's "prism" family): a 2-D Delaunay triangulation extruded -- node valence 4 .. 8:
+                        # 8 wedges = the cube graph, 12 / 16 two-coloured, 10 / 14 neither (the wide kernel's small class)
+                        ("unstructured prisms (2-D Delaunay of a jittered 100^2 grid, 60 layers of wedges)",
+                         lambda: M.delaunay_wedge_mesh(100, 60, seed=0), ("gls",))):
                     mo = make()
                     M.attach_fields(mo, "u", perm="ALH")
                     Io = ninpol_amd.Interpolator(device=local_rank, grid_build="device")

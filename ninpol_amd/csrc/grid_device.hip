@@ -584,12 +584,16 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
     // interior nodes of unstructured meshes: more cells than the kinds above hold, no two-colouring (kernels_gls_mfx.hip, mfx_desc.hpp)
     // (round 4: boundary nodes too -- computed only when the variable flags them Neumann; their boundary faces are one row each)
     const bool small_fits_b = (use_group & 8) && !force_global && g.dim == 3 && ne <= 12 && nf <= 48 && ne + 3 * (nf - nbf) + nbf <= 64;
-    if ((use_group & 32) && !force_global && ne <= kMfxMaxCells && !(nbf == 0 ? small_fits : small_fits_b) &&
+    // (an interior node the small-node kernel could take -- at most 12 cells, 64 rows -- comes here too if it has at least 9 cells: with fronts
+    //  its dense problem is 43 x 19 where the small-node kernel sweeps 55 x 31: the wide kernel's small class, bit 9: NIN_GLS_NO_MFX_SMALL)
+    const bool small_class_candidate = (use_group & 512) && nbf == 0 && small_fits && ne >= 9;
+    if ((use_group & 32) && !force_global && ne <= kMfxMaxCells && (!(nbf == 0 ? small_fits : small_fits_b) || small_class_candidate) &&
         (nbf == 0 || !(use_group & 128))) {
         uint32_t w[kMfxDescWords];
-        const int k = mfx_descriptor(g, (int32_t)p, w);   // 1 + the size class of its dense problem
-        if (k > 0 && nbf == 0) { node_class[p] = (uint8_t)(243 + k - 1); return; }
-        if (k > 0 && k <= 2) { node_class[p] = 242; return; }   // a boundary node that fits 7 x 11 tiles: the boundary instantiation's list
+        const int k = mfx_descriptor(g, (int32_t)p, w);   // 1 + the size class of its dense problem, or kMfxSmallCode
+        if (k == kMfxSmallCode && (use_group & 512)) { node_class[p] = 240; return; }
+        if (k > 0 && nbf == 0 && !small_fits) { node_class[p] = (uint8_t)(243 + (k == kMfxSmallCode ? 1 : k) - 1); return; }
+        if (k > 0 && k <= 2 && nbf > 0) { node_class[p] = 242; return; }   // a boundary node that fits 7 x 11 tiles: the boundary instantiation's list
     }
     // interior nodes beyond the wide kernel's 16 fronts + 21 dense cells (a random point cloud's Delaunay mesh: 6 % of its nodes): the
     // dense problem in global-memory tiles (kernels_gls_mfg.hip, mfg_desc.hpp; bit 8: NIN_GLS_NO_MFG clears it)

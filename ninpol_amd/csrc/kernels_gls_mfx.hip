@@ -41,6 +41,9 @@ constexpr int XROW = 13;
 #define NIN_MFX_TWO_WAVE_TILES 104     // classes of up to this many tiles run at two wavefronts per SIMD (256 registers: the 7 x 11 class spills 256 B,
                                        // the 8 x 13 class 528 B a lane -- and still gain 22 % / 12 % from the second wave: A/B in one session)
 #endif
+#ifndef NIN_MFX_SMALL_WAVES
+#define NIN_MFX_SMALL_WAVES 3          // the (4, 7) class: 28 tiles
+#endif
 template <int TQ, int TCB>
 struct XDims {
     static constexpr int RP = 4 * TCB + 1;               // pitch of R in LDS (odd: lane = row reads are conflict-free)
@@ -48,7 +51,7 @@ struct XDims {
     static constexpr int STAGE = 16 * TQ * XROW, RSZ = NP * RP;
     static constexpr int MAIN = ((STAGE > RSZ ? STAGE : RSZ) + 1) & ~1;
     static constexpr int Y = MAIN, W = Y + 64, Z = W + 40, DESC = Z + 2, PER_WAVE = DESC + kMfxDescWords / 2;
-    static constexpr int WAVES = TQ * TCB <= NIN_MFX_TWO_WAVE_TILES ? 2 : 1;   // wavefronts per SIMD (60 tiles: the registers of half a SIMD lane hold them)
+    static constexpr int WAVES = TQ * TCB <= 32 ? NIN_MFX_SMALL_WAVES : TQ * TCB <= NIN_MFX_TWO_WAVE_TILES ? 2 : 1;   // wavefronts per SIMD (60 tiles: the registers of half a SIMD lane hold them)
 };
 
 // The dense phase of one node: gather the rows from the staging area into TQ x TCB tiles (16 rows x 4 columns each) and factor
@@ -373,11 +376,11 @@ int launch_mfx_desc(const GridView &g, const int32_t *nodes, int32_t count, uint
 int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int cls, int add_neumann, double *out,
                    double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
-    if (cls < 0 || cls > kMfxClasses) return -1;         // (cls == kMfxClasses: the boundary nodes' list)
+    if (cls < 0 || cls > kMfxClasses + 1) return -1;     // (cls == kMfxClasses: the boundary nodes' list, + 1: the small interior class)
     int64_t blocks = count;
     // persistent: one wavefront per workgroup, one (class 0: two) per SIMD -- the register file of a SIMD lane belongs to one (two) node(s)
-    constexpr int tiles[kMfxClasses + 1] = {6 * 10, 7 * 11, 8 * 13, 9 * 15, 10 * 16, 7 * 11};
-    const int64_t cap = 4 * 256 * (tiles[cls] <= NIN_MFX_TWO_WAVE_TILES ? 2 : 1);
+    constexpr int tiles[kMfxClasses + 2] = {6 * 10, 7 * 11, 8 * 13, 9 * 15, 10 * 16, 7 * 11, 4 * 7};
+    const int64_t cap = 4 * 256 * (tiles[cls] <= 32 ? NIN_MFX_SMALL_WAVES : tiles[cls] <= NIN_MFX_TWO_WAVE_TILES ? 2 : 1);
     if (blocks > cap) blocks = cap;
 #define NIN_MFX_LAUNCH(TQ, TCB, BND)                                                                                                      \
     hipLaunchKernelGGL((nin_gls_mfx_kernel<TQ, TCB, BND>), dim3((unsigned)blocks), dim3(64), 0, stream, g, nodes, desc, count, add_neumann, out, \
@@ -387,7 +390,8 @@ int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc
     else if (cls == 2) NIN_MFX_LAUNCH(8, 13, false);
     else if (cls == 3) NIN_MFX_LAUNCH(9, 15, false);
     else if (cls == 4) NIN_MFX_LAUNCH(10, 16, false);
-    else NIN_MFX_LAUNCH(7, 11, true);
+    else if (cls == 5) NIN_MFX_LAUNCH(7, 11, true);
+    else NIN_MFX_LAUNCH(4, 7, false);
 #undef NIN_MFX_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

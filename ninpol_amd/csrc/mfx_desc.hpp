@@ -31,6 +31,11 @@ constexpr int kMfxW0 = 1, kMfxW1 = 17, kMfxSlotTable = 33, kMfxFree0 = 39;
 // Size classes of the dense problem (kernels_gls_mfx.hip: one instantiation and one list of the launch plan each): rows <= 16 TQ,
 // pivot columns nc = 3 D < 4 TCB for (TQ, TCB) = (6, 10), (7, 11), (8, 13), (9, 15), (10, 16)
 constexpr int kMfxClasses = 5;
+// ... and a SMALL class, (4, 7): rows <= 64, nc < 28 -- interior nodes of 10 .. 14 cells that are not two-coloured (an unstructured prism mesh:
+// a node of odd valence 5 or 7 has 10 / 14 wedges in a ring no two-colouring closes: 4 + 6 or 6 + 8 cells, 43 x 19 or 59 x 25).  Its own
+// list of the launch plan (node_class 240), three wavefronts per SIMD.  mfx_descriptor returns kMfxSmallCode for it.
+constexpr int kMfxSmallCode = 7;
+NIN_HD inline bool mfx_fits_small(int F, int D, int nfree, int nbnd) { return nbnd == 0 && 7 * F + D + 3 * nfree <= 64 && 3 * D < 28; }
 NIN_HD inline int mfx_size_class(int F, int D, int nfree, int nbnd) {
     const int rows = 7 * F + D + 3 * nfree + nbnd, nc = 3 * D;
     if (rows <= 96 && nc < 40) return 0;
@@ -84,7 +89,7 @@ __device__ inline bool mfx_graph(const GridView &g, int32_t p, MfxGraph &G) {
     return true;
 }
 
-// 0: not for this kernel; 1 + size class: the words are filled
+// 0: not for this kernel; 1 + size class (or kMfxSmallCode): the words are filled
 __device__ inline int mfx_descriptor(const GridView &g, int32_t p, uint32_t w[kMfxDescWords]) {
     MfxGraph G;
     if (!mfx_graph(g, p, G)) return 0;
@@ -152,6 +157,7 @@ __device__ inline int mfx_descriptor(const GridView &g, int32_t p, uint32_t w[kM
         w[kMfxW0 + f] |= ((uint32_t)fi << (6 + 6 * k)) | ((a_front ? 1u : 0u) << (24 + k));
         w[kMfxW1 + f] |= (uint32_t)rank[oc] << (5 * k);
     }
+    if (mfx_fits_small(F, D, nfree, nbnd)) return kMfxSmallCode;
     return 1 + mfx_size_class(F, D, nfree, nbnd);
 }
 #endif

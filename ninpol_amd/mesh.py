@@ -258,6 +258,51 @@ def delaunay_tet_mesh(n, jitter=0.25, seed=0, lattice="bcc", renumber=True):
     return Mesh(np.ascontiguousarray(pts), [CellBlock("tetra", tets)])
 
 
+def delaunay_wedge_mesh(n, layers=None, jitter=0.3, seed=0, lattice="grid"):
+    """UNSTRUCTURED prisms: the Delaunay triangulation (scipy / Qhull) of a jittered point cloud in the unit square, extruded into
+    `layers` layers of wedges (default n) -- the "prism" mesh class of the reference's numbers (performance.yaml; it ships no mesh
+    files).  A node inside has 2 V wedges around it, V = its valence in the triangulation: 4 .. 9 (the structured wedge_mesh: always
+    6), and the ring of wedges is two-coloured only where V is even.
+
+    lattice = "grid": the (n + 1)^2 lattice points, each moved by U(-jitter, jitter) * h; "random": the lattice points on the
+    boundary + (n - 1)^2 uniform random points inside.  Boundary points stay on their boundary line.  Nodes are numbered layer by
+    layer ((z, y, x) order of their lattice cell), cells layer by layer, bottom triangle counter-clockwise seen from above."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    layers = n if layers is None else layers
+    h = 1.0 / n
+    g = np.arange(n + 1) * h
+    Y, X = np.meshgrid(g, g, indexing="ij")
+    p2 = np.stack([X.ravel(), Y.ravel()], axis=1)
+    on_b = np.any((p2 < 1e-12) | (p2 > 1 - 1e-12), axis=1)
+    if lattice == "grid":
+        d = rng.uniform(-jitter, jitter, size=p2.shape) * h
+    elif lattice == "random":
+        p2 = np.vstack([p2[on_b], rng.uniform(0.2 * h, 1.0 - 0.2 * h, size=((n - 1) ** 2, 2))])
+        on_b = np.arange(len(p2)) < int(on_b.sum())
+        d = np.zeros_like(p2)
+        d[on_b] = rng.uniform(-jitter, jitter, size=(int(on_b.sum()), 2)) * h
+    else:
+        raise ValueError("lattice must be 'grid' or 'random'")
+    for a in range(2):
+        on = (np.abs(p2[:, a]) < 1e-12) | (np.abs(p2[:, a] - 1.0) < 1e-12)
+        d[on, a] = 0.0
+    p2 = p2 + d
+    ij = np.clip(np.floor(p2 / h - 1e-9).astype(np.int64), 0, n - 1)
+    order = np.lexsort((p2[:, 0], ij[:, 0], ij[:, 1]))
+    p2 = p2[order]
+    tri = Delaunay(p2).simplices.astype(np.int64)
+    a, b, c = p2[tri[:, 0]], p2[tri[:, 1]], p2[tri[:, 2]]
+    cw = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0]) < 0
+    tri[cw] = tri[cw][:, [0, 2, 1]]
+    tri = tri[np.lexsort((tri.max(axis=1), tri.min(axis=1)))]
+    per = len(p2)
+    z = np.arange(layers + 1) / layers
+    pts = np.concatenate([np.column_stack([p2, np.full(per, zk)]) for zk in z])
+    w = np.concatenate([np.hstack([tri + k * per, tri + (k + 1) * per]) for k in range(layers)])
+    return Mesh(np.ascontiguousarray(pts), [CellBlock("wedge", w.astype(np.int64))])
+
+
 def quad_tri_mesh_2d(nx, ny=None, jitter=0.0, seed=0):
     """2-D mesh on the unit square: left half quads, right half triangles (each lattice cell cut along its
     0-2 diagonal).  Points are (P, 3) with z = 0, as meshio delivers 2-D meshes."""

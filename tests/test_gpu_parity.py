@@ -46,6 +46,8 @@ def _meshes():
     yield "mixed1266", M.mixed_mesh(12, 6, 6, jitter=0.1, seed=3), "ALH", (2, 1.0)
     yield "delaunay10", M.delaunay_tet_mesh(10, seed=4), "ALH", (2, 0.0)
     yield "delaunay8_random_cloud_fan", M.delaunay_tet_mesh(8, seed=9, lattice="random"), "FAN", (0, 1.0)
+    yield "delaunay_prisms14", M.delaunay_wedge_mesh(14, 8, seed=5), "ALH", (2, 0.0)
+    yield "delaunay_prisms12_random_fan", M.delaunay_wedge_mesh(12, 6, seed=6, lattice="random"), "FAN", (1, 0.0)
 
 
 @pytest.mark.parametrize("name,mesh,perm,plane", list(_meshes()), ids=[m[0] for m in _meshes()])
@@ -488,6 +490,36 @@ def test_gpu_tiles_in_global_memory_kernel_on_a_random_cloud(oracle_lib, monkeyp
     assert sum(b[k] for k in heavy) == sum(d[k] for k in heavy) + d["mfg_tiles"]
     # every interior node of the cloud is on a one-wavefront multifrontal kernel now
     assert d["mfx"] + d["mfg_tiles"] + d["mfw_large"] + d["mfw_small"] + d["mfw_general"] + d["hex8"] >= int(interior.sum()) - int(np.sum(interior & (ne <= 12)))
+
+
+def test_gpu_unstructured_prisms_small_class(oracle_lib, monkeypatch):
+    """Unstructured PRISMS (a 2-D Delaunay triangulation extruded: the reference's "prism" mesh family): a node of valence V has 2 V
+    wedges in a ring; V = 4 is the cube graph (cube-node kernel), V = 6 / 8 are two-coloured (kernels_gls_mfw.hip), V = 5 / 7 / 9 are
+    not: 10- and 14-cell nodes go to the wide kernel's SMALL class (4 x 7 tiles: their dense problem is 43 x 19 / 59 x 25 after the
+    fronts), where the small-node kernel (a dense 55 x 31 sweep) and the (6, 10) class ran before (NIN_GLS_NO_MFX_SMALL: that route)."""
+    mesh = M.delaunay_wedge_mesh(12, 6, seed=3, lattice="random")
+    M.attach_fields(mesh, "u", perm="ALH", neumann_plane=(2, 0.0), seed=4)
+    o = oracle_lib.OracleInterpolator("port", threads=8)
+    o.load_mesh(mesh)
+    wo, no = o.prepare("gls", "u")
+    plans = {}
+    for route in ("default", "NIN_GLS_NO_MFX_SMALL"):
+        with monkeypatch.context() as mp:
+            if route != "default":
+                mp.setenv(route, "1")
+            I = _interp()
+            I.load_mesh(mesh_obj=mesh)
+            w, nw = I.prepare_interpolator("gls", "u", np.arange(I.grid.n_points))
+            plans[route] = I.grid.gls_plan()
+        assert util.rowscaled_err(w, wo) <= util.WEIGHT_RTOL and util.rowscaled_err(nw, no) <= util.WEIGHT_RTOL, route
+        assert util.elementwise_err(w, wo) <= util.elementwise_rtol("gls", "ALH"), route
+    ne = np.diff(np.asarray(I.grid.esup_ptr))
+    interior = ~np.asarray(I.grid.boundary_points).astype(bool)
+    d, b = plans["default"], plans["NIN_GLS_NO_MFX_SMALL"]
+    assert d["mfx_4x7"] == int(np.sum(interior & np.isin(ne, (10, 14)))) > 50 and b["mfx_4x7"] == 0, (d, b)
+    assert b["small12"] == d["small12"] + int(np.sum(interior & (ne == 10))) and b["mfx_6x10"] == d["mfx_6x10"] + int(np.sum(interior & (ne == 14)))
+    assert d["hex8"] == int(np.sum(interior & (ne == 8))) and d["mfw_small"] == int(np.sum(interior & (ne == 12)))
+    assert d["mfx"] == d["mfx_4x7"] + d["mfx_6x10"] + d["mfx_7x11"] + d["mfx_8x13"] + d["mfx_9x15"] + d["mfx_10x16"]
 
 
 def test_gpu_wide_kernel_dense_phase_alone():

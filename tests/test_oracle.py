@@ -42,6 +42,8 @@ def _meshes():
     yield "mixed844", M.mixed_mesh(8, 4, 4, jitter=0.1, seed=3), "ALH", (2, 1.0)
     yield "delaunay6", M.delaunay_tet_mesh(6, seed=5), "ALH", (0, 1.0)
     yield "delaunay5_random_cloud", M.delaunay_tet_mesh(5, seed=6, lattice="random"), "LIN", (2, 0.0)
+    yield "delaunay_prisms8", M.delaunay_wedge_mesh(8, 4, seed=1), "ALH", (2, 0.0)
+    yield "delaunay_prisms7_random", M.delaunay_wedge_mesh(7, 3, seed=2, lattice="random"), "LIN", (0, 1.0)
 
 
 @pytest.mark.parametrize("name,mesh,perm,plane", list(_meshes()), ids=[m[0] for m in _meshes()])

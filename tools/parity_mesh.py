@@ -6,6 +6,7 @@ import ninpol_amd, ninpol_oracle, util
 from ninpol_amd import mesh as M
 cases = {"del8": lambda: M.delaunay_tet_mesh(8, seed=1), "del12": lambda: M.delaunay_tet_mesh(12, seed=2),
          "del16": lambda: M.delaunay_tet_mesh(16, seed=3), "delr10": lambda: M.delaunay_tet_mesh(10, seed=4, lattice="random"),
+         "delw12": lambda: M.delaunay_wedge_mesh(12, 8, seed=2), "delwr12": lambda: M.delaunay_wedge_mesh(12, 8, seed=3, lattice="random"),
          "delr24": lambda: M.delaunay_tet_mesh(24, seed=0, lattice="random"), "delr30": lambda: M.delaunay_tet_mesh(30, seed=3, lattice="random"),
          "tet8": lambda: M.tet_mesh(8, jitter=0.1, seed=1), "mixed": lambda: M.mixed_mesh(10, 6, 6, jitter=0.1, seed=1)}
 ninpol_oracle.build_port()

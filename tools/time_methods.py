@@ -10,6 +10,7 @@ cases = {"tet40": lambda: M.tet_mesh(40, jitter=0.1), "wedge60": lambda: M.wedge
          "mixed10m": lambda: M.mixed_mesh(200, 120, 120, jitter=0.1), "tet10m": lambda: M.tet_mesh(119, jitter=0.1),
          "del24": lambda: M.delaunay_tet_mesh(24, seed=0), "del40": lambda: M.delaunay_tet_mesh(40, seed=0),
          "del54": lambda: M.delaunay_tet_mesh(54, seed=0), "delr24": lambda: M.delaunay_tet_mesh(24, seed=0, lattice="random"),
+         "delw100": lambda: M.delaunay_wedge_mesh(100, 60, seed=0), "delwr100": lambda: M.delaunay_wedge_mesh(100, 60, seed=0, lattice="random"),
          "delr40": lambda: M.delaunay_tet_mesh(40, seed=0, lattice="random"), "delr54": lambda: M.delaunay_tet_mesh(54, seed=0, lattice="random")}
 for name in (sys.argv[1:] or [c for c in cases if not c.endswith(("10m", "80m", "216")) and not c.startswith("del")]):
     m = cases[name](); M.attach_fields(m, "u", perm="ALH")
