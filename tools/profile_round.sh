@@ -17,7 +17,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
   timeout -k 10 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-other-meshes --no-e2e > $OUT/pmc$i.json 2> $OUT/pmc$i.err || { echo "pmc pass $i failed"; tail -5 $OUT/pmc$i.err; exit 1; }
 done
 # the block kernel by size class on the mixed and Kuhn-tet meshes (BASELINE config [3] at size: mixed10m)
-NIN_GRID_BUILD=device timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mixed_tet -- python3 tools/time_methods.py mixed tet40 wedge60 mixed10m del54 delr40 > $OUT/methods_by_mesh.txt 2> $OUT/mixed_tet.err || { echo "mixed/tet pass failed"; tail -5 $OUT/mixed_tet.err; }
+NIN_GRID_BUILD=device timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mixed_tet -- python3 tools/time_methods.py mixed tet40 wedge60 mixed10m del54 delr40 delw100 > $OUT/methods_by_mesh.txt 2> $OUT/mixed_tet.err || { echo "mixed/tet pass failed"; tail -5 $OUT/mixed_tet.err; }
 # issue-side counters of the one-wavefront multifrontal kernel on the Kuhn-tet mesh: the strip form and the row-lane form
 bash tools/pmc_tet.sh $OUT/pmc_tet_strips > $OUT/pmc_tet_strips.txt 2>&1 || echo "tet pmc (strips) failed"
 NIN_MFW_NO_STRIPS=1 bash tools/pmc_tet.sh $OUT/pmc_tet_rows > $OUT/pmc_tet_rows.txt 2>&1 || echo "tet pmc (rows) failed"
