@@ -9,11 +9,11 @@ from ninpol_amd import mesh as M
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", range(21))
+@pytest.mark.parametrize("case", range(25))
 def test_fuzz_case(oracle_lib, case):
     import ninpol_amd
     rng = np.random.default_rng(7000 + case)
-    kind = ["hex", "tet", "wedge", "mixed", "fan"][case % 5] if case < 15 else "delaunay"   # (cases 0 .. 14 are round 3's, unchanged)
+    kind = ["hex", "tet", "wedge", "mixed", "fan"][case % 5] if case < 15 else "delaunay" if case < 21 else "prisms"   # (cases 0 .. 14 are round 3's, unchanged)
     nx, ny, nz = (int(v) for v in rng.integers(3, 9, size=3))
     jit = float(rng.uniform(0.0, 0.2))
     seed = int(rng.integers(1 << 30))
@@ -25,6 +25,8 @@ def test_fuzz_case(oracle_lib, case):
         m = M.wedge_mesh(nx, ny, nz, jitter=min(jit, 0.08), seed=seed)
     elif kind == "mixed":
         m = M.mixed_mesh(max(nx, 4) + 2, ny, nz, jitter=min(jit, 0.1), seed=seed)
+    elif kind == "prisms":     # unstructured prisms: a 2-D Delaunay triangulation (jittered grid, or a random cloud) extruded
+        m = M.delaunay_wedge_mesh(max(nx, 4) + 2, max(nz - 2, 2), jitter=0.1 + jit, seed=seed, lattice="random" if case % 2 == 0 else "grid")
     elif kind == "delaunay":   # unstructured tetrahedra: jittered body-centred cloud or (every third case) a random cloud
         m = M.delaunay_tet_mesh(max(nx, 4), jitter=0.1 + jit, seed=seed, lattice="random" if case % 3 == 0 else "bcc")
     else:

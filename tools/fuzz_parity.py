@@ -14,13 +14,14 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(2026)
 worst = {"idw": 0.0, "ls": 0.0, "gls": 0.0}
 for case in range(n_cases):
-    kind = ["hex", "tet", "wedge", "mixed", "fan", "delaunay"][case % 6]
+    kind = ["hex", "tet", "wedge", "mixed", "fan", "delaunay", "prisms"][case % 7]
     nx, ny, nz = (int(v) for v in rng.integers(3, 9, size=3))
     jit = float(rng.uniform(0.0, 0.2)); seed = int(rng.integers(1 << 30))
     if kind == "hex": m = M.hex_mesh(nx, ny, nz, jitter=jit, seed=seed)
     elif kind == "tet": m = M.tet_mesh(max(nx - 2, 2), max(ny - 2, 2), max(nz - 2, 2), jitter=min(jit, 0.1), seed=seed)
     elif kind == "wedge": m = M.wedge_mesh(nx, ny, nz, jitter=min(jit, 0.08), seed=seed)
     elif kind == "mixed": m = M.mixed_mesh(max(nx, 4) + 2, ny, nz, jitter=min(jit, 0.1), seed=seed)
+    elif kind == "prisms": m = M.delaunay_wedge_mesh(max(nx, 4) + 2, max(nz - 2, 2), jitter=0.1 + jit, seed=seed, lattice="random" if case % 3 == 0 else "grid")
     elif kind == "delaunay": m = M.delaunay_tet_mesh(max(nx, 4), jitter=0.1 + jit, seed=seed, lattice="random" if case % 4 == 0 else "bcc")
     else: m = M.wedge_fan(int(rng.integers(5, 70)), int(rng.integers(2, 4)), jitter=0.02, seed=seed)
     plane = None if rng.random() < 0.3 else (int(rng.integers(0, 3)), float(rng.integers(0, 2)))
