@@ -73,7 +73,11 @@ struct MfwDims {
     static constexpr int NP = 3 * DM, NREG = 7 * FM - 2 * DM, DROW0 = 7 * FM, RP = 3 * DM + 1;
     static constexpr int TOTAL = GENERAL ? kMfwMaxRows : 7 * FM + DM;
     static constexpr int PAD = ROWS_IN_LANES ? 0 : 8;   // zero rows behind the pivot rows: the LDS sweep runs in whole groups of 4 and reads one group ahead
-    static constexpr int STAGE = FM * STAGE_F + (GENERAL ? 18 * kMfwMaxFree : 0);   // phase 1's staging area (fronts' fill rows, free faces' rows)
+    // the strip form stages whole rows of the dense problem, 13 doubles each: [0 0 0 | cell 1 | cell 2 | cell 3 | c] at 13 row (kernels_gls_mfx.hip's
+    // layout: the entry of a column whose cell has code k in the row is at 3 k + component, code 0 = the zeros in front -- no select, no branch)
+    static constexpr int XROW = 13, XSTAGE = (ROWS_IN_LANES && !GENERAL) ? (7 * FM + DM) * XROW : 0;
+    static constexpr int STAGE0 = FM * STAGE_F + (GENERAL ? 18 * kMfwMaxFree : 0);   // phase 1's staging area (fronts' fill rows, free faces' rows)
+    static constexpr int STAGE = STAGE0 > XSTAGE ? STAGE0 : XSTAGE;
     static constexpr int LDS_FS = FM * STAGE_F;
     static constexpr int LDS_R = ((NP + PAD) * RP > STAGE ? (NP + PAD) * RP : STAGE);   // R rows; the staging area lies under them
     static constexpr int LDS_Y = LDS_R, LDS_D = LDS_Y + 3 * DM + 4, LDS_W = LDS_D + 3 * DM + 4, LDS_Z = LDS_W + FM + DM,
@@ -290,7 +294,22 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
             apply_panel<3, true, true, true, true>(P, g3, B);
 #pragma unroll
             for (int t = 0; t < 3; ++t) u[t] = fma(z[2], B[2][t], fma(z[1], B[1][t], z[0] * B[0][t]));
-            if ((lane >> 2) < F) {
+            if constexpr (STRIPS) {
+                if ((lane >> 2) < F) {
+                    // rows 7 f .. 7 f + 6 of the dense problem: the c lane writes c and the row's three zeros, the others their cell's entries
+                    double *stg = Rm + 7 * Dm::XROW * (lane >> 2) + (jq == 0 ? 0 : 3 + 3 * my);
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) {
+                        stg[r * Dm::XROW + 0] = jq == 0 ? 0.0 : B[3 + r][0];
+                        stg[r * Dm::XROW + 1] = jq == 0 ? 0.0 : B[3 + r][1];
+                        stg[r * Dm::XROW + 2] = jq == 0 ? 0.0 : B[3 + r][2];
+                    }
+                    if (jq == 0) {
+#pragma unroll
+                        for (int r = 0; r < 7; ++r) stg[r * Dm::XROW + 12] = B[3 + r][0];
+                    }
+                }
+            } else if ((lane >> 2) < F) {
                 double *stg = Rm + (lane >> 2) * STAGE_F + (jq == 0 ? 9 : 3 * my);
 #pragma unroll
                 for (int r = 0; r < 7; ++r) stg[r * 10] = B[3 + r][0];
@@ -332,6 +351,14 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
         }
         // the dense cells' rows, (x_K - x_v) on the cell's own columns: column 3 d + t <- lane d's component t
         if (lane < D) { dbuf[3 * lane + 0] = dod[0]; dbuf[3 * lane + 1] = dod[1]; dbuf[3 * lane + 2] = dod[2]; }
+        if constexpr (STRIPS) {
+            if (lane < D) {   // ... and, strip form, as row 7 FM + d of the staged problem (c = 1)
+                double *cd = Rm + Dm::XROW * (Dm::DROW0 + lane);
+                cd[0] = 0.0; cd[1] = 0.0; cd[2] = 0.0;
+                cd[3] = dod[0]; cd[4] = dod[1]; cd[5] = dod[2];
+                cd[12] = 1.0;
+            }
+        }
         NIN_MFW_STAMP(2);   // phase 1 done
         wave_lds_sync();
 
@@ -351,23 +378,21 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
                 tbl = (1u << (2 * s0)) | (2u << (2 * s1)) | (3u << (2 * s2));
                 tbl = lane < F ? tbl : 0u;
             }
-            // per tile row q, this lane's row of the dense problem: rtbl = the 2-bit codes of its non-zero column slots, rb = the LDS
-            // index of the entry code 1 points at (slot code c lies 3 (c - 1) further on), rbc = where its c entry is.  A fill row
-            // of front f: the front's table, its staged row, that row's 10th entry.  The cell row of dense cell d: code 1 at slot
-            // d only, (x_K - x_v) in dbuf, a one.  No row: no codes, zeros.
-            int rb[NQ], rbc[NQ];
-            uint32_t rtbl[NQ];
+            // per tile row q, this lane's row of the dense problem: rtbl = the 2-bit codes of its cells' column slots, rbz = the byte address
+            // of the staged row (a row the node does not have: row 0, with no codes -- its three leading zeros), rbc = of its c entry
+            uint32_t rtbl[NQ], rbz[NQ], rbc[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int row = 16 * q + 4 * sb + si;
                 const bool fill = row < Dm::DROW0;
-                const int f = fill ? (row * 37) >> 8 : 0, i = row - 7 * f, d = row - Dm::DROW0;
+                const int f = fill ? (row * 37) >> 8 : 0, d = row - Dm::DROW0;
                 const uint32_t ft = (uint32_t)__shfl((int)tbl, f);
                 const bool ok = fill ? f < F : d < D;
                 rtbl[q] = ok ? (fill ? ft : 1u << (2 * d)) : 0u;
-                rb[q] = fill ? f * STAGE_F + i * 10 : Dm::LDS_D + 3 * d;
-                rbc[q] = ok ? (fill ? rb[q] + 9 : Dm::LDS_Z + 64) : Dm::LDS_Z;
+                rbz[q] = ok ? 8u * Dm::XROW * (uint32_t)row : 0u;
+                rbc[q] = ok ? 8u * (Dm::XROW * (uint32_t)row + 12u) : 8u * (uint32_t)Dm::LDS_Z;
             }
+            const char *const Rb = reinterpret_cast<const char *>(Rm);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 // (sjq: sj behind an opaque move, fresh per column block -- otherwise the column arithmetic of all ten blocks is
@@ -375,15 +400,15 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
                 int sjq;
                 asm volatile("v_mov_b32 %0, %1" : "=v"(sjq) : "v"(sj));
                 const int col = 4 * cb + sjq;
-                const int sd = (col * 43) >> 7, tt3 = col - 3 * sd - 3;                          // column = component tt of dense slot sd
-                const bool is_c = col == nc;
+                const int sd = (col * 43) >> 7;                                                 // column = component tt of dense slot sd
+                const uint32_t tt8 = 8u * (uint32_t)(col - 3 * sd);
                 const int sh = col < nc ? 2 * sd : 30;                                          // (slot 15: nobody's neighbour)
+                const uint32_t cmask = col == nc ? 0xFFFFFFFFu : 0u;                            // this lane's column of this block is c
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int code = (int)((rtbl[q] >> sh) & 3u);
-                    int off = code ? rb[q] + 3 * code + tt3 : Dm::LDS_Z;
-                    off = is_c ? rbc[q] : off;
-                    C[q][cb] = Rm[off];
+                    const uint32_t code = (rtbl[q] >> sh) & 3u;
+                    const uint32_t a = rbz[q] + 24u * code + tt8;
+                    C[q][cb] = *reinterpret_cast<const double *>(Rb + ((rbc[q] & cmask) | (a & ~cmask)));
                 }
             }
             wave_lds_sync();          // the staging area is R's from here on
