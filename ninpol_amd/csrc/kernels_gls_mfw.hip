@@ -70,7 +70,8 @@ constexpr int STAGE_F = 70;   // per front: 7 fill rows x (9 neighbour columns +
 // the pivot rows live in LDS -- row t of R replaces pivot row t in place -- and the other NREG in registers.
 template <int FM, int DM, bool ROWS_IN_LANES, bool GENERAL>
 struct MfwDims {
-    static constexpr int NP = 3 * DM, NREG = 7 * FM - 2 * DM, DROW0 = 7 * FM, RP = 3 * DM + 1;
+    static constexpr int NP = 3 * DM, NREG = 7 * FM - 2 * DM, DROW0 = 7 * FM;
+    static constexpr int RP = 4 * ((NP + 1 + 3) / 4) + 1;   // pitch of R in LDS: whole column blocks of four (the strip form stores a pivot row's blocks unguarded) + 1 (odd: no bank conflicts)
     static constexpr int TOTAL = GENERAL ? kMfwMaxRows : 7 * FM + DM;
     static constexpr int PAD = ROWS_IN_LANES ? 0 : 8;   // zero rows behind the pivot rows: the LDS sweep runs in whole groups of 4 and reads one group ahead
     // the strip form stages whole rows of the dense problem, 13 doubles each: [0 0 0 | cell 1 | cell 2 | cell 3 | c] at 13 row (kernels_gls_mfx.hip's

@@ -184,10 +184,12 @@ __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc,
     }
     NIN_SUB(ST, 0);   // panel factored
     // rows 4 p .. 4 p + steps - 1 of R are final after this panel: tile Q0, quad bp.  The panel block's own entries now:
+    // (every lane of the pivot rows stores: below the diagonal and right of c that is a reflector's entry or a zero in a word of R's row
+    //  nobody reads -- one exec region per panel instead of one per store)
     const bool r_rows = sb == bp && si < steps;
     const int col0 = 4 * p + sj;
     double *dst = Rm + (4 * p + si) * RP + col0;
-    if (r_rows && sj >= si && col0 <= nc) dst[0] = C[Q0][0];
+    if (r_rows) dst[0] = C[Q0][0];
     // (a panel with fewer than four pivots is the last one: c sits in its block, nothing lies to the right of it)
     if (NT > 0 && steps == 4) {
         // T came out of the steps, row si in this lane; as a strip, negated: -T[k][i] at lane (k = si, ., i = sj)
@@ -220,9 +222,7 @@ __device__ __forceinline__ void strip_panel(double (&C)[NQ][NCB], int p, int nc,
         NIN_SUB(ST, 3);   // update
         if (r_rows) {
 #pragma unroll
-            for (int cb = 1; cb <= NT; ++cb) {
-                if (col0 + 4 * cb <= nc) dst[4 * cb] = C[Q0][cb - 1];
-            }
+            for (int cb = 1; cb <= NT; ++cb) dst[4 * cb] = C[Q0][cb - 1];
         }
     }
     NIN_SUB(ST, 4);   // rows of R stored
