@@ -625,10 +625,10 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
             int kb = (nc - 1) & ~3;
             double c4[4], n4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) c4[j] = (lane < nc && kb + j < nc) ? Rl[kb + j] : 0.0;
+            for (int j = 0; j < 4; ++j) c4[j] = (STRIPS || (lane < nc && kb + j < nc)) ? Rl[kb + j] : 0.0;   // (strip form: unguarded -- a column right of nc is a word of the row nobody uses, a lane beyond nc reads row 0 in vain; an exec region per load otherwise)
             for (; kb >= 0; kb -= 4) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) n4[j] = (lane < nc && kb >= 4) ? Rl[kb - 4 + j] : 0.0;
+                for (int j = 0; j < 4; ++j) n4[j] = STRIPS ? Rl[(kb >= 4 ? kb - 4 : 0) + j] : (lane < nc && kb >= 4) ? Rl[kb - 4 + j] : 0.0;
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     const int k = kb + j;

@@ -302,10 +302,10 @@ __global__ __launch_bounds__(64, (XDims<TQ, TCB>::WAVES)) void nin_gls_mfx_kerne
             int kb = (nc - 1) & ~3;
             double c4[4], n4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) c4[j] = (lane < nc && kb + j < nc) ? Rl[kb + j] : 0.0;
+            for (int j = 0; j < 4; ++j) c4[j] = Rl[kb + j];   // (unguarded: a column right of nc is a word of the row nobody uses, a lane beyond nc reads row 0 in vain)
             for (; kb >= 0; kb -= 4) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) n4[j] = (lane < nc && kb >= 4) ? Rl[kb - 4 + j] : 0.0;
+                for (int j = 0; j < 4; ++j) n4[j] = Rl[(kb >= 4 ? kb - 4 : 0) + j];
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {
                     const int k = kb + j;
