@@ -57,8 +57,13 @@ struct XDims {
 // The dense phase of one node: gather the rows from the staging area into TQ x TCB tiles (16 rows x 4 columns each) and factor
 // (mfw_strips.hpp's unrolled strip_factor<TQ, TCB>: straight-line, sweeps the whole class size).
 template <int TQ, int TCB, bool BND>
-__device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, int nc, int nrows, int F, int D, int nfree, int nbnd, int lane) {
+__device__ __forceinline__ double dense_phase(double *Rm, const uint32_t *dl, int nc, int nrows, int F, int D, int nfree, int nbnd, int lane_) {
     using Dm = XDims<TQ, TCB>;
+    // (the lane number behind an opaque move, fresh per node: everything the dense phase derives from it -- row / quad / column indices, the
+    //  identity strip, the masks of the panel steps -- is otherwise hoisted out of the node loop, lives across phase 1 and ends up in scratch,
+    //  to come back word by word inside the panels, each behind a full wait)
+    int lane;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_));
     const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
     double C[TQ][TCB];
     // code(sd) = 1 + the index of dense slot sd among the row's cells (0: not one of them), two bits per slot; a front's
