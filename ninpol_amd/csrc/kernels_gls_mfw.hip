@@ -369,7 +369,12 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
             // ---- the dense problem in 16 x 4 tiles, panels of four reflectors through the matrix unit (strip_factor) ---------
             static_assert(ROWS_IN_LANES && !GENERAL, "the strip form serves the two-coloured kinds");
             constexpr int NQ = (Dm::TOTAL + 15) / 16, NCB = (NP + 1 + 3) / 4;
-            const int si = lane >> 4, sb = (lane >> 2) & 3, sj = lane & 3;
+            // (the lane number behind an opaque move, fresh per node: what the dense phase derives from it -- row / quad / column indices, the
+            //  identity strip, the panel steps' masks -- is otherwise hoisted out of the node loop, lives across phase 1 and comes back from
+            //  scratch word by word inside the panels; kernels_gls_mfx.hip: -9 % on a Delaunay mesh)
+            int ln;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
+            const int si = ln >> 4, sb = (ln >> 2) & 3, sj = ln & 3;
             double C[NQ][NCB];
             // per tile row: where this lane's row lives in the staging area.  code(sd) = 1 + the index of dense slot sd among
             // the front's three neighbours (0: not a neighbour), two bits per slot, made once per front (lane f) and shuffled
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
             ST.on = stamping; ST.last = __builtin_amdgcn_s_memtime();
             for (int j = 0; j < 6; ++j) ST.acc[j] = 0;
 #endif
-            rr = strip_factor<NQ, NCB>(C, nc, lane, Rm, RP, ST);
+            rr = strip_factor<NQ, NCB>(C, nc, ln, Rm, RP, ST);
 #ifdef NIN_MFW_STAMPS
             if (stamping && lane == 0) for (int j = 0; j < 5; ++j) nws[nodes[8 + j]] = (double)ST.acc[j];
 #endif
