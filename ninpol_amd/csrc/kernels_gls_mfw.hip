@@ -432,8 +432,10 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
             // ---- the dense problem, lane = ROW.  TWO arrays (large): lane r holds row NP + r (r < NREG) in a[] and pivot row
             //      r (r < NP) in b[]; one array (small): lane r holds row r in b[], the pivot rows first --------------------------
             constexpr int TOTAL = Dm::TOTAL;
+            int ln;                                                  // (opaque, fresh per node: see the strip form above)
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
             constexpr bool TWO = TOTAL > 64;
-            static_assert(TOTAL <= 128 && NP <= 64, "one row per lane and array");
+            static_assert(TOTAL <= 128 && NP <= 64, "one row per ln and array");
             double a[NP], b[NP], ca = 0.0, cb;
             {
                 auto gather = [&](int row, bool have, double (&x)[NP], double &xc) {
@@ -472,22 +474,22 @@ __global__ __launch_bounds__(256, (FM <= kMfwSmallFronts ? 3 : 2)) void nin_gls_
                     xc = ok ? (fill ? Rm[fbase + 9] : free_row ? 0.0 : 1.0) : 0.0;
                 };
                 if constexpr (TWO) {
-                    gather(NP + lane, NP + lane < TOTAL, a, ca);
-                    const int rb = lane < NP ? lane : lane + 64;         // b[]: the pivot rows, then the rows a[] has no lane for
+                    gather(NP + ln, NP + ln < TOTAL, a, ca);
+                    const int rb = ln < NP ? ln : ln + 64;         // b[]: the pivot rows, then the rows a[] has no lane for
                     gather(rb < TOTAL ? rb : 0, rb < TOTAL, b, cb);
                 } else {
 #pragma unroll
                     for (int i = 0; i < NP; ++i) a[i] = 0.0;
-                    gather(lane < TOTAL ? lane : 0, lane < TOTAL, b, cb);
+                    gather(ln < TOTAL ? ln : 0, ln < TOTAL, b, cb);
                 }
             }
             wave_lds_sync();          // the staging area is R's from here on
             NIN_MFW_STAMP(3);   // rows gathered
             // the first reflector: |column 0|^2 by a wave reduction (the later ones come out of the steps)
             Reflector h = reflector(rl64(b[0], 0), wave_allsum(TWO ? fma(a[0], a[0], b[0] * b[0]) : b[0] * b[0]));
-            for (int k = 0; k < D; ++k) rows_block<NP, TWO>(a, b, ca, cb, h, k, nc, lane, Rm, RP);
-            if (lane < nc) Rm[lane * RP + nc] = cb;                  // (Q^T c)(0:nc), the last column of R
-            const double cbl = lane >= nc ? cb : 0.0;                // rows that never were pivot rows (one array; or D < DM) count too
+            for (int k = 0; k < D; ++k) rows_block<NP, TWO>(a, b, ca, cb, h, k, nc, ln, Rm, RP);
+            if (ln < nc) Rm[ln * RP + nc] = cb;                  // (Q^T c)(0:nc), the last column of R
+            const double cbl = ln >= nc ? cb : 0.0;                // rows that never were pivot rows (one array; or D < DM) count too
             rr = wave_allsum(TWO ? fma(ca, ca, cbl * cbl) : cbl * cbl);   // r . r = |(Q^T c)(nc:)|^2
         } else {
         // ---- the dense problem, lane = column: rows 0 .. NP-1 (fill rows of the first fronts) go to LDS, the others
