@@ -63,7 +63,7 @@ PLAN_KERNEL_NAMES = {   # kernel of the launch plan -> its name in a rocprofv3 t
     "mfw_general": "nin_gls_mfw_kernel<12, 15, true, true, false>", "small4": "nin_gls_small_kernel<4>",
     "small8": "nin_gls_small_kernel<8>", "small12": "nin_gls_small_kernel<12>", "quad4": "nin_gls_quad4_kernel", "mfx_6x10": "nin_gls_mfx_kernel<6, 10, false>", "mfx_7x11": "nin_gls_mfx_kernel<7, 11, false>",
     "mfx_8x13": "nin_gls_mfx_kernel<8, 13, false>", "mfx_9x15": "nin_gls_mfx_kernel<9, 15, false>", "mfx_10x16": "nin_gls_mfx_kernel<10, 16, false>",
-    "mfx_boundary": "nin_gls_mfx_kernel<7, 11, true>", "mfg_tiles": "nin_gls_mfg_kernel", "mfx_4x7": "nin_gls_mfx_kernel<4, 7, false>"}
+    "mfx_boundary": "nin_gls_mfx_kernel<7, 11, true>", "mfg_tiles": "nin_gls_mfg_kernel", "mfx_4x7": "nin_gls_mfx_kernel<4, 7, false>", "mfx_7x12": "nin_gls_mfx_kernel<7, 12, false>"}
 
 
 def gls_kernel_rows(grid, launch, time_launches, reps=3):

@@ -200,9 +200,9 @@ const char *nin_kernel_name(int method);
  * 128 x 52, 144 x 60, 160 x 64 (rows x columns), counts[18]: its list of BOUNDARY nodes (computed only when flagged Neumann),
  * counts[19]: the multifrontal kernel whose dense problem lives in global-memory tiles (interior nodes beyond the wide kernel: up to 32 fronts +
  * 40 dense cells, 256 x 121), counts[20]: the wide kernel's SMALL class (interior nodes of 9 .. 14 cells that are not two-coloured: at most
- * 64 x 28).  (Diagnostics and tests: the reference has one code path, gls.pyx:138-197,
+ * 64 x 28), counts[21]: its class (7, 12) -- at most 112 x 48, between 112 x 44 and 128 x 52.  (Diagnostics and tests: the reference has one code path, gls.pyx:138-197,
  * for every node.) */
-int nin_gls_plan(const nin_grid *g, int64_t counts[21]);
+int nin_gls_plan(const nin_grid *g, int64_t counts[22]);
 
 /* Measurement: the FP64 flops one GLS launch performs, kernel by kernel of the launch plan (numbered as in
  * nin_gls_plan): alg[k] = ALGORITHMIC flops of the formulation kernel k runs on its nodes (fronts + dense rest for the
@@ -210,7 +210,7 @@ int nin_gls_plan(const nin_grid *g, int64_t counts[21]);
  * one-wavefront block / global-scratch kernels), ref[k] = the reference's dense dgels on the same nodes (gls.pyx:420-474),
  * computed[k] = the nodes that are computed at all (Dirichlet boundary nodes and nodes outside the parity set get the zero row).
  * Needs nin_fields_set (the Neumann flags decide which boundary nodes are computed). */
-int nin_gls_plan_flops(nin_grid *g, double alg[21], double ref[21], int64_t computed[21]);
+int nin_gls_plan_flops(nin_grid *g, double alg[22], double ref[22], int64_t computed[22]);
 
 /* ---- multi-GPU: the all-gather of the path as direct peer-to-peer writes ------------------------------------------
  * Replaces nothing in the reference (it is single-process); it is the exchange step north_star adds -- "a single allgatherv to

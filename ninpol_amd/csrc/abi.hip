@@ -485,6 +485,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
                           (getenv("NIN_GLS_NO_SMALL") == nullptr ? 8 : 0) |         // (bit 3: the one-wavefront dense kernel for small nodes)
                           (getenv("NIN_GLS_NO_QUAD4") == nullptr ? 16 : 0) |        // (bit 4: the two-lanes-per-node kernel for quad nodes)
                           (getenv("NIN_GLS_NO_MFX") == nullptr ? 32 : 0) |          // (bit 5: the wide multifrontal kernel: unstructured meshes)
+                          (getenv("NIN_GLS_NO_MFX_7X12") == nullptr ? 1024 : 0) |    // (bit 10: ... its class (7, 12))
                           (getenv("NIN_GLS_NO_MFX_SMALL") == nullptr ? 512 : 0) |    // (bit 9: ... its small class (4, 7) for interior nodes of 9 .. 14 cells)
                           (getenv("NIN_GLS_NO_MFG") == nullptr ? 256 : 0) |          // (bit 8: the multifrontal kernel on global-memory tiles: nodes beyond the wide kernel)
                           (getenv("NIN_GLS_MFX_NO_BOUNDARY") != nullptr ? 128 : 0) | // (bit 7: ... leaves the boundary nodes to the block kernel: round 3's route)
@@ -519,6 +520,7 @@ int nin_grid_to_device(nin_grid *g, int device) {
         else if (c >= 243 && c <= 247) mfx_list[c - 243].push_back((int32_t)p);
         else if (c == 242) mfx_list[5].push_back((int32_t)p);
         else if (c == 240) mfx_list[6].push_back((int32_t)p);
+        else if (c == 239) mfx_list[7].push_back((int32_t)p);
         else if (c == 241) mfg_list.push_back((int32_t)p);
         else lists[c].push_back((int32_t)p);
     }
@@ -713,7 +715,7 @@ static int gls_side_begin(DeviceGrid &d, int add_neumann, double *out, double *n
     const auto &k = d.gls[kGlsClasses - 1];
     int rc = 0;
     if (ng > 0)
-        rc = launch_gls_mfg(d.v, d.mfg.nodes + bg, d.mfg_desc + (size_t)kMfgDescWords * bg, ng, add_neumann, out, nws, d.gls_queue + 15, d.mfg_tiles, d.mfg_slots, side);
+        rc = launch_gls_mfg(d.v, d.mfg.nodes + bg, d.mfg_desc + (size_t)kMfgDescWords * bg, ng, add_neumann, out, nws, d.gls_queue + 16, d.mfg_tiles, d.mfg_slots, side);
     if (!rc && n > 0)
         rc = launch_gls_class(d.v, k.nodes ? k.nodes + b : nullptr, n, 0, k.rows_per_lane, add_neumann, out, nws, d.gls_scratch, d.gls_scratch_stride,
                               d.gls_scratch_slots, side);
@@ -745,10 +747,10 @@ static int launch_gls_but_cube(DeviceGrid &d, int add_neumann, double *out, doub
     for (int i = 0; i < 3 && !rc; ++i)
         if (on(9 + i)) rc = launch_gls_small(d.v, d.small[i].nodes, d.small[i].count, i, add_neumann, out, nws, stream);
     if (!rc && on(12)) rc = launch_gls_quad4(d.v, d.quad4.nodes, d.quad4_desc, d.quad4.count, add_neumann, out, nws, stream);
-    for (int i = 0; i < DeviceGrid::kMfxLists && !rc; ++i)   // (work counters: ints 8 .. 14; list 6 -- the small class -- is kernel 20 of the plan)
-        if (on(i < 6 ? 13 + i : 20)) rc = launch_gls_mfx(d.v, d.mfx[i].nodes, d.mfx_desc[i], d.mfx[i].count, i, add_neumann, out, nws, d.gls_queue + 8 + i, stream);
-    if (!rc && on(19) && !d.side_pending)   // (work counter: int 15)
-        rc = launch_gls_mfg(d.v, d.mfg.nodes, d.mfg_desc, d.mfg.count, add_neumann, out, nws, d.gls_queue + 15, d.mfg_tiles, d.mfg_slots, stream);
+    for (int i = 0; i < DeviceGrid::kMfxLists && !rc; ++i)   // (work counters: ints 8 .. 15; lists 6 and 7 -- the small class, (7, 12) -- are kernels 20 and 21 of the plan)
+        if (on(i < 6 ? 13 + i : 14 + i)) rc = launch_gls_mfx(d.v, d.mfx[i].nodes, d.mfx_desc[i], d.mfx[i].count, i, add_neumann, out, nws, d.gls_queue + 8 + i, stream);
+    if (!rc && on(19) && !d.side_pending)   // (work counter: int 16)
+        rc = launch_gls_mfg(d.v, d.mfg.nodes, d.mfg_desc, d.mfg.count, add_neumann, out, nws, d.gls_queue + 16, d.mfg_tiles, d.mfg_slots, stream);
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         if ((c == kGlsClasses - 1 && d.side_pending) || !on(c)) continue;
         rc = launch_class(d, c, d.gls[c].nodes, d.gls[c].count, add_neumann, out, nws, stream);
@@ -804,6 +806,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else if (c >= 243 && c <= 247) c = kGlsClasses + 8 + (c - 243);   // the wide multifrontal kernel, by size class
         else if (c == 242) c = kGlsClasses + 8 + 5;                       // ... its boundary nodes
         else if (c == 240) c = kGlsClasses + 8 + 6;                       // ... its small interior class
+        else if (c == 239) c = kGlsClasses + 8 + 7;                       // ... its class (7, 12)
         else if (c == 241) c = kGlsClasses + 8 + DeviceGrid::kMfxLists;   // the multifrontal kernel on global-memory tiles
         lists[c].push_back((int32_t)targets[i]);
     }
@@ -865,7 +868,7 @@ int nin_weights_device(nin_grid *g, int method, const int64_t *targets, int64_t 
         else if (method == NIN_METHOD_LS) rc = launch_ls(d.v, dl, cnt, 0, 0, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses) rc = launch_hex8(d, dl, ddesc, cnt, add_neumann, dev_csr_data, dev_neumann_ws, stream);
         else if ((int)c == kGlsClasses + 8 + DeviceGrid::kMfxLists)
-            rc = launch_gls_mfg(d.v, dl, dmfg, cnt, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue + 15, d.mfg_tiles, d.mfg_slots, stream);
+            rc = launch_gls_mfg(d.v, dl, dmfg, cnt, add_neumann, dev_csr_data, dev_neumann_ws, d.gls_queue + 16, d.mfg_tiles, d.mfg_slots, stream);
         else if ((int)c >= kGlsClasses + 8)
             rc = launch_gls_mfx(d.v, dl, dmfx + kMfxDescWords * (first[c] - first[kGlsClasses + 8]), cnt, (int)c - kGlsClasses - 8, add_neumann, dev_csr_data,
                                 dev_neumann_ws, d.gls_queue + 8 + ((int)c - kGlsClasses - 8), stream);
@@ -1033,7 +1036,7 @@ int weights_chunk(nin_grid *g, int method, int k, double *out, double *nws, hipS
     if (!rc && !d.side_pending) {
         constexpr int li = kGlsClasses + 8 + DeviceGrid::kMfxLists;
         const int32_t b = d.chunk_off[li][k], n = d.chunk_off[li][k + 1] - b;
-        if (n > 0) rc = launch_gls_mfg(d.v, d.mfg.nodes + b, d.mfg_desc + (size_t)kMfgDescWords * b, n, 1, out, nws, d.gls_queue + 15, d.mfg_tiles, d.mfg_slots, stream);
+        if (n > 0) rc = launch_gls_mfg(d.v, d.mfg.nodes + b, d.mfg_desc + (size_t)kMfgDescWords * b, n, 1, out, nws, d.gls_queue + 16, d.mfg_tiles, d.mfg_slots, stream);
     }
     for (int c = 0; c < kGlsClasses && !rc; ++c) {
         const int32_t b = d.chunk_off[c][k], n = d.chunk_off[c][k + 1] - b;
@@ -1311,7 +1314,7 @@ double dense_flops(int64_t ne, int64_t n_if, int64_t n_nb) {
 double dgels_flops(double m, double n, double nrhs) { return 2 * m * n * n - 2 * n * n * n / 3 + nrhs * (4 * m * n - 2 * n * n) + nrhs * n * n; }
 }  // namespace
 
-int nin_gls_plan_flops(nin_grid *g, double alg[21], double ref[21], int64_t computed[21]) {
+int nin_gls_plan_flops(nin_grid *g, double alg[22], double ref[22], int64_t computed[22]) {
     if (!g || !alg || !ref || !computed) return fail(NIN_EINVAL, "NULL argument");
     DeviceGrid &d = g->d;
     HostGrid &h = g->h;
@@ -1319,7 +1322,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[21], double ref[21], int64_t comp
     if (!d.fields_set || !d.flag_staging) return fail(NIN_ESTATE, "nin_fields_set has not been called (the Neumann flags decide which boundary nodes are computed)");
     if (h.ensure(A_ESUP_PTR | A_ESUP | A_FSUP_PTR | A_FSUP | A_ESUF)) return fail(NIN_EHIP, "mirroring the connectivity failed");
     HIP_TRY(hipSetDevice(d.device));
-    for (int k = 0; k < 21; ++k) { alg[k] = ref[k] = 0.0; computed[k] = 0; }
+    for (int k = 0; k < 22; ++k) { alg[k] = ref[k] = 0.0; computed[k] = 0; }
     const int64_t P = h.n_points;
     // (F, D, free faces) of the nodes of the multifrontal kernels: from their descriptors
     std::vector<uint32_t> fdq((size_t)P, 0u);
@@ -1339,7 +1342,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[21], double ref[21], int64_t comp
     if (read_desc(d.mfg.nodes, d.mfg_desc, d.mfg.count, kMfgDescWords, 0)) return fail(NIN_EHIP, "reading the descriptors back failed");
     for (int64_t p = 0; p < P; ++p) {
         const int c = g->node_class[p];
-        const int k = c == 255 ? 5 : (c >= 252 && c <= 254) ? 6 + (254 - c) : (c >= 249 && c <= 251) ? 9 + (c - 249) : c == 248 ? 12 : (c >= 243 && c <= 247) ? 13 + (c - 243) : c == 242 ? 18 : c == 241 ? 19 : c == 240 ? 20 : c;
+        const int k = c == 255 ? 5 : (c >= 252 && c <= 254) ? 6 + (254 - c) : (c >= 249 && c <= 251) ? 9 + (c - 249) : c == 248 ? 12 : (c >= 243 && c <= 247) ? 13 + (c - 243) : c == 242 ? 18 : c == 241 ? 19 : c == 240 ? 20 : c == 239 ? 21 : c;
         const int fl = d.flag_staging[p];
         if ((fl & 1) && !(fl & 2)) continue;                   // a Dirichlet boundary node: the zero row, nothing computed (gls.pyx:165-166)
         const int64_t eb = h.esup_ptr[p], ne = h.esup_ptr[p + 1] - eb, fb = h.fsup_ptr[p], nf = h.fsup_ptr[p + 1] - fb;
@@ -1397,7 +1400,7 @@ int nin_gls_plan_flops(nin_grid *g, double alg[21], double ref[21], int64_t comp
     return NIN_OK;
 }
 
-int nin_gls_plan(const nin_grid *g, int64_t counts[21]) {
+int nin_gls_plan(const nin_grid *g, int64_t counts[22]) {
     if (!g || !counts) return fail(NIN_EINVAL, "NULL argument");
     if (g->d.device < 0 || g->d.prebuilt) return fail(NIN_ENODEVICE, "grid is not on a device (call nin_grid_to_device first)");
     for (int c = 0; c < kGlsClasses; ++c) counts[c] = g->d.gls[c].count;
@@ -1410,6 +1413,7 @@ int nin_gls_plan(const nin_grid *g, int64_t counts[21]) {
     for (int i = 0; i < 6; ++i) counts[13 + i] = g->d.mfx[i].count;
     counts[19] = g->d.mfg.count;
     counts[20] = g->d.mfx[6].count;
+    counts[21] = g->d.mfx[7].count;
     return NIN_OK;
 }
 

@@ -85,9 +85,9 @@ struct DeviceGrid {
     uint32_t *mfw_desc[3] = {nullptr, nullptr, nullptr};   // [kMfwDescWords * mfw[i].count] descriptor words
     // kernels_gls_mfx.hip (mfx_desc.hpp): interior nodes of unstructured meshes, up to 16 fronts + 21 dense cells, one list per size
     // class of the dense problem (6 x 10, 7 x 11, 8 x 13, 9 x 15, 10 x 16 tiles)
-    static constexpr int kMfxLists = 7;   // (the sixth: boundary nodes, kernels_gls_mfx.hip's BND instantiation; the seventh: the small interior class (4, 7))
+    static constexpr int kMfxLists = 8;   // (the sixth: boundary nodes, kernels_gls_mfx.hip's BND instantiation; the seventh: the small interior class (4, 7); the eighth: (7, 12))
     GlsClass mfx[kMfxLists];
-    uint32_t *mfx_desc[kMfxLists] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [kMfxDescWords * mfx[c].count] descriptor words
+    uint32_t *mfx_desc[kMfxLists] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [kMfxDescWords * mfx[c].count] descriptor words
     // kernels_gls_mfg.hip (mfg_desc.hpp): interior nodes beyond the wide kernel's registers (up to 32 fronts + 40 dense cells): the tiles
     // of the dense problem in a global-memory slot per resident wavefront
     GlsClass mfg;

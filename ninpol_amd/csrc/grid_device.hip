@@ -592,7 +592,8 @@ __global__ void k_classify(GridView g, int use_group, int force_global, uint8_t 
         uint32_t w[kMfxDescWords];
         const int k = mfx_descriptor(g, (int32_t)p, w);   // 1 + the size class of its dense problem, or kMfxSmallCode
         if (k == kMfxSmallCode && (use_group & 512)) { node_class[p] = 240; return; }
-        if (k > 0 && nbf == 0 && !small_fits) { node_class[p] = (uint8_t)(243 + (k == kMfxSmallCode ? 1 : k) - 1); return; }
+        if (k == kMfxMidCode && (use_group & 1024)) { node_class[p] = 239; return; }            // (bit 10: NIN_GLS_NO_MFX_7X12 clears it: class (8, 13))
+        if (k > 0 && nbf == 0 && !small_fits) { node_class[p] = (uint8_t)(243 + (k == kMfxSmallCode ? 1 : k == kMfxMidCode ? 3 : k) - 1); return; }
         if (k > 0 && k <= 2 && nbf > 0) { node_class[p] = 242; return; }   // a boundary node that fits 7 x 11 tiles: the boundary instantiation's list
     }
     // interior nodes beyond the wide kernel's 16 fronts + 21 dense cells (a random point cloud's Delaunay mesh: 6 % of its nodes): the

@@ -381,10 +381,10 @@ int launch_mfx_desc(const GridView &g, const int32_t *nodes, int32_t count, uint
 int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc, int32_t count, int cls, int add_neumann, double *out,
                    double *nws, int32_t *queue, hipStream_t stream) {
     if (count <= 0) return 0;
-    if (cls < 0 || cls > kMfxClasses + 1) return -1;     // (cls == kMfxClasses: the boundary nodes' list, + 1: the small interior class)
+    if (cls < 0 || cls > kMfxClasses + 2) return -1;     // (cls == kMfxClasses: the boundary nodes' list, + 1: the small interior class, + 2: (7, 12))
     int64_t blocks = count;
     // persistent: one wavefront per workgroup, one (class 0: two) per SIMD -- the register file of a SIMD lane belongs to one (two) node(s)
-    constexpr int tiles[kMfxClasses + 2] = {6 * 10, 7 * 11, 8 * 13, 9 * 15, 10 * 16, 7 * 11, 4 * 7};
+    constexpr int tiles[kMfxClasses + 3] = {6 * 10, 7 * 11, 8 * 13, 9 * 15, 10 * 16, 7 * 11, 4 * 7, 7 * 12};
     const int64_t cap = 4 * 256 * (tiles[cls] <= 32 ? NIN_MFX_SMALL_WAVES : tiles[cls] <= NIN_MFX_TWO_WAVE_TILES ? 2 : 1);
     if (blocks > cap) blocks = cap;
 #define NIN_MFX_LAUNCH(TQ, TCB, BND)                                                                                                      \
@@ -396,7 +396,8 @@ int launch_gls_mfx(const GridView &g, const int32_t *nodes, const uint32_t *desc
     else if (cls == 3) NIN_MFX_LAUNCH(9, 15, false);
     else if (cls == 4) NIN_MFX_LAUNCH(10, 16, false);
     else if (cls == 5) NIN_MFX_LAUNCH(7, 11, true);
-    else NIN_MFX_LAUNCH(4, 7, false);
+    else if (cls == 6) NIN_MFX_LAUNCH(4, 7, false);
+    else NIN_MFX_LAUNCH(7, 12, false);
 #undef NIN_MFX_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

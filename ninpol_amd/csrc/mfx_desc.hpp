@@ -35,6 +35,10 @@ constexpr int kMfxClasses = 5;
 // a node of odd valence 5 or 7 has 10 / 14 wedges in a ring no two-colouring closes: 4 + 6 or 6 + 8 cells, 43 x 19 or 59 x 25).  Its own
 // list of the launch plan (node_class 240), three wavefronts per SIMD.  mfx_descriptor returns kMfxSmallCode for it.
 constexpr int kMfxSmallCode = 7;
+// ... and one BETWEEN (7, 11) and (8, 13): (7, 12) -- rows <= 112, nc < 48.  45 % of the nodes of a body-centred Delaunay mesh that miss (7, 11)
+// fit it and would sweep 104 tiles for 84 otherwise (node_class 239, plan entry mfx_7x12; mfx_descriptor returns kMfxMidCode).
+constexpr int kMfxMidCode = 8;
+NIN_HD inline bool mfx_fits_mid(int F, int D, int nfree, int nbnd) { return nbnd == 0 && 7 * F + D + 3 * nfree <= 112 && 3 * D < 48; }
 NIN_HD inline bool mfx_fits_small(int F, int D, int nfree, int nbnd) { return nbnd == 0 && 7 * F + D + 3 * nfree <= 64 && 3 * D < 28; }
 NIN_HD inline int mfx_size_class(int F, int D, int nfree, int nbnd) {
     const int rows = 7 * F + D + 3 * nfree + nbnd, nc = 3 * D;
@@ -158,7 +162,9 @@ __device__ inline int mfx_descriptor(const GridView &g, int32_t p, uint32_t w[kM
         w[kMfxW1 + f] |= (uint32_t)rank[oc] << (5 * k);
     }
     if (mfx_fits_small(F, D, nfree, nbnd)) return kMfxSmallCode;
-    return 1 + mfx_size_class(F, D, nfree, nbnd);
+    const int cls = mfx_size_class(F, D, nfree, nbnd);
+    if (cls == 2 && mfx_fits_mid(F, D, nfree, nbnd)) return kMfxMidCode;
+    return 1 + cls;
 }
 #endif
 

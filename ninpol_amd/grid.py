@@ -190,12 +190,12 @@ class Grid:
         _lib.check(_lib.load().nin_grid_release_scratch(self._h))
 
     PLAN_KERNELS = ("block1", "block2", "block4", "block8", "scratch", "hex8", "mfw_large", "mfw_small", "mfw_general", "small4", "small8",
-                    "small12", "quad4", "mfx_6x10", "mfx_7x11", "mfx_8x13", "mfx_9x15", "mfx_10x16", "mfx_boundary", "mfg_tiles", "mfx_4x7")
+                    "small12", "quad4", "mfx_6x10", "mfx_7x11", "mfx_8x13", "mfx_9x15", "mfx_10x16", "mfx_boundary", "mfg_tiles", "mfx_4x7", "mfx_7x12")
 
     def gls_plan_flops(self):
         """Per kernel of the GLS launch plan (nin_gls_plan_flops): {kernel: (algorithmic flops, reference-equivalent dgels flops,
         nodes computed)} for one launch over all nodes; needs the fields on the device (a DevicePlan or an interpolate() first)."""
-        alg, ref, comp = np.zeros(21), np.zeros(21), np.zeros(21, dtype=np.int64)
+        alg, ref, comp = np.zeros(22), np.zeros(22), np.zeros(22, dtype=np.int64)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         _lib.check(_lib.load().nin_gls_plan_flops(self._h, p(alg), p(ref), p(comp)))
         return {k: (float(alg[i]), float(ref[i]), int(comp[i])) for i, k in enumerate(self.PLAN_KERNELS)}
@@ -205,6 +205,6 @@ class Grid:
         node and global scratch, the cube-node kernel, the one-wavefront multifrontal kernel (two-coloured nodes large / small, general kind), the one-wavefront dense
         kernel for small nodes (at most 4 / 8 / 12 cells), the two-lanes-per-node kernel for the nodes inside a boundary
         face of a hexahedron mesh, the wide one-wavefront multifrontal kernel (interior nodes of unstructured meshes)."""
-        counts = np.zeros(21, dtype=np.int64)
+        counts = np.zeros(22, dtype=np.int64)
         _lib.check(_lib.load().nin_gls_plan(self._h, counts.ctypes.data_as(ctypes.c_void_p)))
         return _PlanCounts(zip(self.PLAN_KERNELS, counts.tolist()))

@@ -426,7 +426,7 @@ def test_gpu_wide_multifrontal_kernel_on_unstructured_tetrahedra(oracle_lib, mon
     o.load_mesh(mesh)
     wo, no = o.prepare("gls", "u")
     plans = {}
-    for route in ("default", "NIN_GLS_MFW_GENERAL", "NIN_GLS_NO_MFX", "NIN_GLS_MFX_NO_BOUNDARY"):
+    for route in ("default", "NIN_GLS_MFW_GENERAL", "NIN_GLS_NO_MFX", "NIN_GLS_MFX_NO_BOUNDARY", "NIN_GLS_NO_MFX_7X12"):
         if route != "default":
             monkeypatch.setenv(route, "1")
         I = _interp()
@@ -448,6 +448,11 @@ def test_gpu_wide_multifrontal_kernel_on_unstructured_tetrahedra(oracle_lib, mon
     # default, the block / small-node kernels with NIN_GLS_MFX_NO_BOUNDARY (round 3's route) -- same weights either way (above)
     assert plans["default"]["mfx_boundary"] > 0 and plans["NIN_GLS_MFX_NO_BOUNDARY"]["mfx_boundary"] == 0
     assert plans["NIN_GLS_MFX_NO_BOUNDARY"]["mfx"] == plans["default"]["mfx"]
+    # the class between (7, 11) and (8, 13): its nodes are (8, 13)'s with NIN_GLS_NO_MFX_7X12 -- same weights either way (above)
+    assert plans["NIN_GLS_NO_MFX_7X12"]["mfx_7x12"] == 0 and plans["NIN_GLS_NO_MFX_7X12"]["mfx"] == plans["default"]["mfx"]
+    assert plans["NIN_GLS_NO_MFX_7X12"]["mfx_8x13"] == plans["default"]["mfx_8x13"] + plans["default"]["mfx_7x12"]
+    if lattice == "bcc":
+        assert plans["default"]["mfx_7x12"] > 0
 
 
 @pytest.mark.parametrize("perm", ["ALH", "FAN"])
@@ -519,7 +524,7 @@ def test_gpu_unstructured_prisms_small_class(oracle_lib, monkeypatch):
     assert d["mfx_4x7"] == int(np.sum(interior & np.isin(ne, (10, 14)))) > 50 and b["mfx_4x7"] == 0, (d, b)
     assert b["small12"] == d["small12"] + int(np.sum(interior & (ne == 10))) and b["mfx_6x10"] == d["mfx_6x10"] + int(np.sum(interior & (ne == 14)))
     assert d["hex8"] == int(np.sum(interior & (ne == 8))) and d["mfw_small"] == int(np.sum(interior & (ne == 12)))
-    assert d["mfx"] == d["mfx_4x7"] + d["mfx_6x10"] + d["mfx_7x11"] + d["mfx_8x13"] + d["mfx_9x15"] + d["mfx_10x16"]
+    assert d["mfx"] == d["mfx_4x7"] + d["mfx_6x10"] + d["mfx_7x11"] + d["mfx_7x12"] + d["mfx_8x13"] + d["mfx_9x15"] + d["mfx_10x16"]
 
 
 def test_gpu_wide_kernel_dense_phase_alone():
